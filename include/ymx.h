@@ -1,0 +1,190 @@
+/* ymx — C ABI of the MI355X (gfx950) detector hot path.
+ *
+ * The reference (Jex-y/yolo, TensorFlow/Keras) has no native or FFI layer: its
+ * hot path is reached through Python modules only.  Each entry point below
+ * therefore cites the Python symbol of the reference whose device work it
+ * carries; the Python package in yolo_amd/ keeps those symbols' names and
+ * signatures and calls these functions through ctypes.
+ *
+ * Conventions
+ *  - every pointer named x/w/y/boxes/scores/... is DEVICE memory owned by the
+ *    caller; the library never allocates, frees or synchronises, never changes
+ *    the current device, and launches on the stream it is given (a hipStream_t
+ *    passed as void*; NULL = the default stream);
+ *  - arguments documented as "host" are small host arrays read during the call;
+ *  - activations are NHWC, contiguous unless a pixel stride (ld, in elements)
+ *    is given; element types are named by YMX_F32 / YMX_BF16;
+ *  - return value: YMX_OK or a negative YMX_E* code; ymx_last_error() returns a
+ *    thread-local message for the last failing call on this thread.
+ */
+#ifndef YMX_H
+#define YMX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YMX_VERSION 100
+
+enum { YMX_F32 = 0, YMX_BF16 = 1 };
+enum { YMX_ACT_NONE = 0, YMX_ACT_LEAKY = 1, YMX_ACT_MISH = 2 };
+enum {
+    YMX_OK = 0,
+    YMX_EARG = -1,        /* bad argument (null pointer, non-positive size, misalignment) */
+    YMX_EUNSUPPORTED = -2,/* shape / dtype combination no kernel covers */
+    YMX_EWORKSPACE = -3,  /* workspace too small */
+    YMX_ELAUNCH = -4      /* HIP reported a launch error */
+};
+
+int ymx_version(void);
+const char *ymx_last_error(void);
+
+/* ---- convolution block ------------------------------------------------------
+ * Replaces YOLOConv.call — layers.py:86-90 with the stack built at layers.py:46-81
+ * ([ZeroPadding2D top/left] -> Conv2D -> [BatchNormalization] -> [Mish|LeakyReLU])
+ * and the shortcut add of ResidialBlock.call, layers.py:100-106.
+ *
+ *   y = act( conv(x, w) * scale + shift ) + residual
+ *
+ * stride 1: SAME padding ((k-1)/2 each side), layers.py:55-57.
+ * stride 2: one zero row/column on the top/left only, then VALID, layers.py:46-54.
+ * scale == NULL means 1 (plain bias in shift: use_bias = not batchNormalization,
+ * layers.py:61); with batch norm the caller folds it: scale = gamma/sqrt(var+eps),
+ * shift = beta - mean*scale (layers.py:4-15 forces inference statistics).
+ * residual == NULL means no shortcut.  act: YMX_ACT_*; leaky slope is 0.1
+ * (layers.py:76).
+ *
+ * w is the PACKED kernel produced by ymx_pack_weights from the reference's HWIO
+ * fp32 layout.  dtype is the storage type of x, residual and the MFMA operands
+ * (accumulation is always fp32).  scale/shift are fp32 [Cout].
+ */
+size_t ymx_packed_weight_bytes(int k, int Cin, int Cout, int dtype);
+int ymx_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype,
+                     void *stream);
+
+int ymx_conv2d_fused(const void *x, const void *w, const void *scale, const void *shift,
+                     const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
+                     int k, int stride, int act, int dtype, void *stream);
+
+/* Same, with explicit pixel strides (elements; 0 = dense), a separate input
+ * element type for the direct (Cin not a multiple of 8) path, and an output
+ * element type (the head's three linear output convs, detectors.py:20,33,43, are
+ * written as fp32 for the decode that follows). */
+int ymx_conv2d_fused_ex(const void *x, const void *w, const void *scale, const void *shift,
+                        const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
+                        int k, int stride, int act, int dtype, int x_dtype, int out_dtype,
+                        int x_ld, int res_ld, int y_ld, void *stream);
+
+/* ---- upsample + concat ------------------------------------------------------
+ * Replaces Upsample.call (layers.py:37-39: tf.image.resize bilinear x2, half-pixel
+ * centres, edge clamp) fused with the tf.concat that follows it at
+ * detectors.py:57-59 and 70-72:  y[..., :C1] = skip,  y[..., C1:] = up2(x).
+ * skip [B,2H,2W,C1] (NULL with C1 = 0 for a bare upsample), x [B,H,W,C2],
+ * y [B,2H,2W,C1+C2]. */
+int ymx_upsample2x_concat(const void *skip, const void *x, void *y, int B, int H, int W,
+                          int C1, int C2, int dtype, void *stream);
+
+/* ---- whole-network executor -------------------------------------------------
+ * Replaces the Python layer loops Darknet53.call (backbones.py:44-60) and
+ * YoloV3.call (detectors.py:46-77): a pre-planned list of the two ops above,
+ * launched back to back on one stream by a single call. */
+typedef struct ymx_op {
+    int32_t kind;                 /* 1 = conv2d_fused_ex, 2 = upsample2x_concat */
+    int32_t B, H, W, Cin, Cout, k, stride, act;
+    int32_t dtype, x_dtype, out_dtype;
+    int32_t x_ld, res_ld, y_ld;
+    int32_t C1, C2;               /* upsample2x_concat only */
+    const void *x, *w, *scale, *shift, *residual;   /* residual doubles as skip */
+    void *y;
+} ymx_op;
+int ymx_run_program(const ymx_op *ops /* host */, int n_ops, void *stream);
+
+/* ---- decode (+ score filter) ------------------------------------------------
+ * Replaces decode / decode_predict (utils.py:107-126, 133-140) for all scales at
+ * once, and with filter != 0 also filter_bboxes (utils.py:142-167):
+ *   xy = (sigmoid(t_xy)*xyscale - 0.5*(xyscale-1) + grid) * stride
+ *   wh = exp(t_wh) * anchor            (anchors in pixels)
+ *   score[c] = sigmoid(t_conf) * sigmoid(t_c)
+ * Candidates are ordered scale by scale, and (row, col, anchor) inside a scale.
+ *
+ * filter == 0: boxes[b][n] = (cx,cy,w,h) pixels for every candidate, counts[b] = N.
+ * filter != 0: only candidates with max_c score >= thr survive, in their original
+ *   order (order-preserving compaction), boxes = (ymin,xmin,ymax,xmax)/image_size,
+ *   src_idx[b][m] = index of survivor m in the unfiltered list, counts[b] = number
+ *   of survivors (survivors beyond cap are counted but not written).
+ *
+ * head[s]: [B,S[s],S[s],3,5+C] (head_dtype);  boxes [B,cap,4] fp32;
+ * scores fp32 CLASS-MAJOR [B,C,cap] (element (b,m,c) at (b*C+c)*cap+m; cap % 4 == 0);
+ * src_idx [B,cap] (may be NULL when filter == 0); counts [B].
+ * anchors host [n_scales][3][2], strides/xyscale host [n_scales]. */
+size_t ymx_decode_workspace_bytes(int B, int n_scales, const int *S /* host */);
+int ymx_decode_filter(const void *const *head /* host array of device ptrs */, int n_scales,
+                      const int *S /* host */, int B, int C, int head_dtype,
+                      const float *anchors, const float *strides, const float *xyscale,
+                      int filter, float thr, float image_size, float *boxes, float *scores,
+                      int *src_idx, int *counts, int cap, void *workspace, size_t ws_bytes,
+                      void *stream);
+
+/* decode (utils.py:107-126) with objectness and class probability kept apart, as
+ * decode and decode_train (utils.py:128-131) return them: boxes [B,cap,4] xywh
+ * pixels, conf [B,cap] = sigmoid(t_conf), prob class-major [B,C,cap] = sigmoid(t_c). */
+int ymx_decode_split(const void *const *head, int n_scales, const int *S, int B, int C,
+                     int head_dtype, const float *anchors, const float *strides,
+                     const float *xyscale, float *boxes, float *conf, float *prob, int *counts,
+                     int cap, void *stream);
+
+/* filter_bboxes (utils.py:142-167) on already decoded tensors: xywh [B,N,4] fp32
+ * dense; scores addressed as scores[b*sb + n*sn + c*sc] (element strides), so both
+ * candidate-major and class-major inputs work.  Outputs as ymx_decode_filter with
+ * filter != 0. */
+size_t ymx_filter_workspace_bytes(int B, int N);
+int ymx_filter_boxes(const float *xywh, const float *scores, long long sb, long long sn,
+                     long long sc, int B, int N, int C, float thr, float image_size,
+                     float *boxes, float *out_scores, int *src_idx, int *counts, int cap,
+                     void *workspace, size_t ws_bytes, void *stream);
+
+/* ---- combined NMS -----------------------------------------------------------
+ * Replaces tf.image.combined_non_max_suppression as called by bbox_nms,
+ * utils.py:184-192 (boxes shared by all classes, clip_boxes, no per-class padding).
+ * Semantics (TensorFlow's kernel is not part of the reference tree, so they are
+ * fixed here): per (image, class) candidates are those with score > score_thr,
+ * visited by descending score, equal scores by ascending candidate index; a
+ * candidate is kept iff its IoU with every box already kept for the class is
+ * <= iou_thr; at most per_class are kept.  Per image the kept entries of all
+ * classes are ordered by descending score, then ascending class, then ascending
+ * index, and the first `total` are emitted with coordinates clipped to [0,1].
+ *
+ * boxes [B,cap,4] (ymin,xmin,ymax,xmax), scores class-major [B,C,cap] fp32,
+ * counts [B] (NULL = cap candidates each), src_idx [B,cap] or NULL.
+ * out_boxes [B,total,4], out_scores [B,total], out_classes [B,total] (fp32),
+ * out_valid [B], out_keep_idx [B,total] (candidate index, mapped through src_idx
+ * when given; -1 padding).  Limits: per_class <= 64, C*per_class <= 8192,
+ * C <= 2048, cap <= 2097152, cap % 4 == 0. */
+size_t ymx_nms_workspace_bytes(int B, int C, int per_class);
+int ymx_nms_combined(const float *boxes, const float *scores, const int *counts,
+                     const int *src_idx, int B, int cap, int C, int per_class, int total,
+                     float iou_thr, float score_thr, float *out_boxes, float *out_scores,
+                     float *out_classes, int *out_valid, int *out_keep_idx, void *workspace,
+                     size_t ws_bytes, void *stream);
+
+/* ---- stand-alone per-channel affine + activation -----------------------------
+ * Replaces Mish.call (layers.py:21-22: x*tanh(softplus(x))) and the inference form
+ * of BatchNormalization.call (layers.py:11-15) when those layers are used on their
+ * own: y = act(x*scale[c] + shift[c]) on [n_pix, C]; scale/shift may be NULL. */
+int ymx_affine_act(const void *x, const float *scale, const float *shift, void *y,
+                   long long n_pix, int C, int act, int dtype, void *stream);
+
+/* ---- box IoU ----------------------------------------------------------------
+ * Replaces bbox_iou (utils.py:33-63) and, with giou != 0, bbox_giou
+ * (utils.py:65-105) on n pairs of centre-format (cx,cy,w,h) fp32 boxes that the
+ * caller has already broadcast to a common shape; zero unions divide to 0
+ * (tf.math.divide_no_nan). */
+int ymx_bbox_iou(const float *b1, const float *b2, float *out, long long n, int giou,
+                 void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YMX_H */

@@ -1,0 +1,246 @@
+"""torch-CPU fp32 restatement of the reference's conv blocks, backbone and head.
+
+Test infrastructure only (see ``oracle/__init__.py``); parity unpinned: the
+convolution, batch-norm and bilinear-resize arithmetic of the reference is
+TensorFlow's, which cannot run here; this file restates their published
+definitions.
+
+Follows
+  /root/reference/layers.py:17-22    Mish
+  /root/reference/layers.py:33-39    Upsample (tf.image.resize bilinear, TF2
+                                     half-pixel centres, no antialias)
+  /root/reference/layers.py:41-90    YOLOConv
+  /root/reference/layers.py:92-106   ResidialBlock
+  /root/reference/backbones.py:6-60  Darknet53
+  /root/reference/detectors.py:4-77  YoloV3
+
+Tensors are NHWC and kernels HWIO at this module's interface, as in the
+reference; torch's NCHW/OIHW is used only inside ``yolo_conv``.
+
+A network is described by a flat list of *conv specs* in execution order, the
+same order the product package uses for its parameters, so one list of
+parameter dicts drives both.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3          # Keras BatchNormalization default epsilon (layers.py:4)
+LEAKY_ALPHA = 0.1      # layers.py:76
+
+
+def mish(x):
+    """x * tanh(softplus(x)); layers.py:22."""
+    return x * torch.tanh(F.softplus(x))
+
+
+def activation(x, act):
+    if act in (None, False, "", "none"):
+        return x
+    if act == "mish":
+        return mish(x)
+    if act == "leaky":
+        return F.leaky_relu(x, LEAKY_ALPHA)
+    if callable(act):
+        return act(x)
+    raise ValueError("Activation should either be a function or one of \"leaky\" or \"mish\".")
+
+
+def yolo_conv(x, p, downsample=False, act="mish"):
+    """One YOLOConv block on an NHWC tensor; layers.py:46-81.
+
+    p: dict with 'kernel' [kh,kw,Cin,Cout] and either 'bias' [Cout] or the
+    batch-norm tensors 'gamma','beta','mean','var' (use_bias = not
+    batchNormalization, layers.py:61).  downsample: pad 1 row on top and 1
+    column on the left only, then stride-2 VALID (layers.py:46-54); otherwise
+    stride-1 SAME (layers.py:55-57).
+    """
+    w = p["kernel"].permute(3, 2, 0, 1).contiguous()          # HWIO -> OIHW
+    xn = x.permute(0, 3, 1, 2)
+    kh, kw = p["kernel"].shape[0], p["kernel"].shape[1]
+    if downsample:
+        xn = F.pad(xn, (1, 0, 1, 0))                           # left, right, top, bottom
+        y = F.conv2d(xn, w, p.get("bias"), stride=2, padding=0)
+    else:
+        # TF SAME at stride 1 with an odd kernel pads (k-1)/2 on every side.
+        y = F.conv2d(xn, w, p.get("bias"), stride=1, padding=((kh - 1) // 2, (kw - 1) // 2))
+    if "gamma" in p:
+        scale = p["gamma"] / torch.sqrt(p["var"] + BN_EPS)
+        shift = p["beta"] - p["mean"] * scale
+        y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    y = activation(y, act)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def upsample2x(x):
+    """Bilinear x2 on NHWC, half-pixel centres, edge clamp; layers.py:37-39."""
+    y = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+# ---------------------------------------------------------------------------
+# Network description: flat conv-spec lists in execution order.
+# Each spec: (kh, cin, cout, downsample, act)
+# ---------------------------------------------------------------------------
+
+def darknet53_specs():
+    """52 conv specs of Darknet53 in call order; backbones.py:10-42."""
+    specs = [(3, 3, 32, False, "mish"), (3, 32, 64, True, "mish")]
+
+    def res(n, f1, f2):
+        for _ in range(n):
+            specs.append((1, f2, f1, False, "mish"))
+            specs.append((3, f1, f2, False, "mish"))
+
+    res(1, 32, 64)
+    specs.append((3, 64, 128, True, "mish"))
+    res(2, 64, 128)
+    specs.append((3, 128, 256, True, "mish"))
+    res(8, 128, 256)
+    specs.append((3, 256, 512, True, "mish"))
+    res(8, 256, 512)
+    specs.append((3, 512, 1024, True, "mish"))
+    res(4, 512, 1024)
+    return specs
+
+
+def yolov3_specs(num_classes):
+    """21 conv specs of YoloV3 in *attribute* order (layer_stack_1, lbbox,
+    layer_stack_2, mbbox, sbbox); detectors.py:10-44."""
+    nout = 3 * (num_classes + 5)
+    s = []
+    cin = 1024
+    for k, c in ((1, 512), (3, 1024), (1, 512), (3, 1024), (1, 512)):
+        s.append((k, cin, c, False, "mish")); cin = c
+    s.append((3, 512, 1024, False, "mish"))
+    s.append((1, 1024, nout, False, None))
+    cin = 512 + 512
+    for k, c in ((1, 512), (3, 1024), (1, 512), (3, 1024), (1, 512)):
+        s.append((k, cin, c, False, "mish")); cin = c
+    s.append((3, 512, 1024, False, "mish"))
+    s.append((1, 1024, nout, False, None))
+    cin = 256 + 512
+    for k, c in ((1, 512), (3, 1024), (1, 512), (3, 1024), (1, 512), (3, 1024)):
+        s.append((k, cin, c, False, "mish")); cin = c
+    s.append((1, 1024, nout, False, None))
+    return s
+
+
+def init_params(specs, seed=0, init="reference", batch_norm=False, bn_random=False):
+    """Random parameters for a spec list, drawn on the CPU from one generator.
+
+    init='reference': kernel ~ N(0, 0.01^2), bias 0 (layers.py:62-63).
+    init='variance' : kernel ~ N(0, 2/K), K = kh*kw*Cin, bias ~ N(0, 0.1^2), so
+                      that activations keep a usable scale through 70+ layers.
+    batch_norm: replace the bias by BN tensors (identity statistics unless
+    bn_random) for every spec that has an activation.
+    """
+    g = torch.Generator().manual_seed(seed)
+    params = []
+    for (k, cin, cout, _down, act) in specs:
+        if init == "reference":
+            std = 0.01
+        else:
+            std = math.sqrt(2.0 / (k * k * cin))
+        p = {"kernel": torch.randn(k, k, cin, cout, generator=g) * std}
+        if batch_norm and act is not None:
+            if bn_random:
+                p["gamma"] = 1.0 + 0.2 * torch.randn(cout, generator=g)
+                p["beta"] = 0.1 * torch.randn(cout, generator=g)
+                p["mean"] = 0.1 * torch.randn(cout, generator=g)
+                p["var"] = 0.5 + torch.rand(cout, generator=g)
+            else:
+                p["gamma"] = torch.ones(cout); p["beta"] = torch.zeros(cout)
+                p["mean"] = torch.zeros(cout); p["var"] = torch.ones(cout)
+        else:
+            p["bias"] = torch.zeros(cout) if init == "reference" else 0.1 * torch.randn(cout, generator=g)
+        params.append(p)
+    return params
+
+
+def darknet53_forward(params, x, act="mish", round_fn=None):
+    """x [B,S,S,3] -> (scale_1 [B,S/8,S/8,256], scale_2 [..,512], scale_3 [..,1024]).
+
+    backbones.py:44-60.  ResidialBlock adds the shortcut after the second
+    activation (layers.py:100-106).  round_fn, if given, is applied to every
+    block output (used to emulate bf16 activation storage).
+    """
+    specs = darknet53_specs()
+    rf = round_fn if round_fn is not None else (lambda t: t)
+    it = iter(zip(specs, params))
+
+    def conv(x):
+        (k, cin, cout, down, a), p = next(it)
+        return yolo_conv(x, p, down, act if a is not None else None)
+
+    def res(x):
+        y = rf(conv(x))
+        y = conv(y)
+        return rf(x + y)
+
+    x = rf(conv(x)); x = rf(conv(x))
+    x = res(x)
+    x = rf(conv(x))
+    for _ in range(2): x = res(x)
+    x = rf(conv(x))
+    for _ in range(8): x = res(x)
+    s1 = x
+    x = rf(conv(x))
+    for _ in range(8): x = res(x)
+    s2 = x
+    x = rf(conv(x))
+    for _ in range(4): x = res(x)
+    s3 = x
+    return s1, s2, s3
+
+
+def yolov3_forward(params, s1, s2, s3, num_classes, act="mish", round_fn=None):
+    """(scale_1, scale_2, scale_3) -> (sbbox, mbbox, lbbox) raw conv maps.
+
+    detectors.py:46-77: five convs at /32, lbbox branch, upsample + concat
+    [scale_2, up], five convs, mbbox branch, upsample + concat [scale_1, up],
+    seven convs ending in sbbox.  The three output convs have no activation.
+    """
+    specs = yolov3_specs(num_classes)
+    rf = round_fn if round_fn is not None else (lambda t: t)
+    it = iter(zip(specs, params))
+
+    def conv(x, final=False):
+        (k, cin, cout, down, a), p = next(it)
+        y = yolo_conv(x, p, down, act if a is not None else None)
+        return y if final else rf(y)
+
+    x = s3
+    for _ in range(5): x = conv(x)
+    l = conv(x); l = conv(l, final=True)
+    x = rf(upsample2x(x))
+    x = torch.cat([s2, x], dim=-1)
+    for _ in range(5): x = conv(x)
+    m = conv(x); m = conv(m, final=True)
+    x = rf(upsample2x(x))
+    s = torch.cat([s1, x], dim=-1)
+    for _ in range(6): s = conv(s)
+    s = conv(s, final=True)
+    return s, m, l
+
+
+def detector_forward(bparams, hparams, x, num_classes, act="mish", round_fn=None):
+    s1, s2, s3 = darknet53_forward(bparams, x, act, round_fn)
+    return yolov3_forward(hparams, s1, s2, s3, num_classes, act, round_fn)
+
+
+def bf16_round(t):
+    """Round-trip through bfloat16 (round to nearest even), staying fp32."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def round_params_bf16(params):
+    """Kernel weights rounded to bf16 (what the bf16 HIP path stores); the
+    epilogue vectors (bias / BN) stay fp32."""
+    out = []
+    for p in params:
+        q = dict(p)
+        q["kernel"] = bf16_round(p["kernel"])
+        out.append(q)
+    return out

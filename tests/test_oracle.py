@@ -1,0 +1,277 @@
+"""CPU tests of the oracle itself: hand-derived known answers, the numpy and C
+restatements against each other, and both against the committed golden fixtures.
+
+The reference has no tests or golden vectors (it cannot be imported here either:
+TensorFlow is absent), so nothing below pins TensorFlow's arithmetic: parity unpinned.
+"""
+import glob
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+from oracle import net_torch as N
+from oracle import postproc_np as P
+
+F = np.float32
+
+
+# ----------------------------------------------------------------------------- decode
+def test_decode_known_answers():
+    """utils.py:107-126 by hand on a 2x2 grid, 2 classes, scale 0 (stride 8, xyscale 1.2,
+    anchors (12,16),(19,36),(40,28))."""
+    t = np.zeros((1, 2, 2, 3, 7), F)
+    # cell (row 0, col 1), anchor 2: t_x = ln 3 -> sigmoid 0.75 ; t_w = ln 2 ; conf logit ln 3
+    t[0, 0, 1, 2, 0] = math.log(3.0)
+    t[0, 0, 1, 2, 2] = math.log(2.0)
+    t[0, 0, 1, 2, 4] = math.log(3.0)
+    t[0, 0, 1, 2, 6] = -math.log(3.0)
+    xywh, conf, prob = P.decode(t, 0, 2, 2)
+    # all-zero logits: sigmoid 0.5 -> (0.5*1.2 - 0.1 + g)*8 = (0.5+g)*8 ; wh = anchor
+    np.testing.assert_allclose(xywh[0, 1, 0, 0], [4.0, 12.0, 12.0, 16.0], rtol=1e-6)   # row 1, col 0
+    np.testing.assert_allclose(xywh[0, 1, 1, 1], [12.0, 12.0, 19.0, 36.0], rtol=1e-6)
+    # the edited cell: x = (0.75*1.2 - 0.1 + 1)*8 = 14.4 ; y = (0.5+0)*8 = 4 ; w = 2*40 ; h = 28
+    np.testing.assert_allclose(xywh[0, 0, 1, 2], [14.4, 4.0, 80.0, 28.0], rtol=1e-6)
+    np.testing.assert_allclose(conf[0, 0, 1, 2, 0], 0.75, rtol=1e-6)
+    np.testing.assert_allclose(prob[0, 0, 1, 2], [0.5, 0.25], rtol=1e-6)
+    bx, sc = P.decode_predict(t, 0, 2, 2)
+    assert bx.shape == (1, 12, 4) and sc.shape == (1, 12, 2)
+    # flatten order (row, col, anchor): row 0, col 1, anchor 2 -> index 5
+    np.testing.assert_allclose(sc[0, 5], [0.375, 0.1875], rtol=1e-6)
+    np.testing.assert_allclose(sc[0, 0], [0.25, 0.25], rtol=1e-6)
+    tr = P.decode_train(t, 0, 2, 2)
+    assert tr.shape == (1, 2, 2, 3, 7)
+    np.testing.assert_allclose(tr[0, 0, 1, 2], [14.4, 4.0, 80.0, 28.0, 0.75, 0.5, 0.25], rtol=1e-6)
+
+
+def test_decode_scales_use_their_own_constants():
+    t = np.zeros((1, 1, 1, 3, 6), F)
+    for s, (stride, anc) in enumerate(((8, (12, 16)), (16, (36, 75)), (32, (142, 110)))):
+        xywh, _, _ = P.decode(t, s, 1, 1)
+        np.testing.assert_allclose(xywh[0, 0, 0, 0], [0.5 * stride, 0.5 * stride, anc[0], anc[1]], rtol=1e-6)
+
+
+def test_filter_known_answers():
+    """utils.py:142-167: >= threshold, order kept, (cy-h/2, cx-w/2, cy+h/2, cx+w/2)/size."""
+    boxes = np.array([[[10, 20, 4, 8], [30, 40, 10, 20], [50, 60, 2, 2], [5, 5, 2, 4]]], F)
+    scores = np.array([[[0.1, 0.25], [0.2, 0.1], [0.9, 0.0], [0.25, 0.3]]], F)
+    fb, fs, counts, src = P.filter_bboxes(boxes, scores, 0.25, 100.0)
+    assert counts.tolist() == [3] and src.tolist() == [[0, 2, 3]]
+    np.testing.assert_allclose(fb[0, 0], [0.16, 0.08, 0.24, 0.12], rtol=1e-6)
+    np.testing.assert_allclose(fb[0, 1], [0.59, 0.49, 0.61, 0.51], rtol=1e-6)
+    np.testing.assert_array_equal(fs[0], scores[0, [0, 2, 3]])
+    # per-image counts differ, padding is zero / -1
+    boxes2 = np.concatenate([boxes, boxes], 0)
+    scores2 = np.concatenate([scores, scores * 0.5], 0)
+    fb, fs, counts, src = P.filter_bboxes(boxes2, scores2, 0.25, 100.0)
+    assert counts.tolist() == [3, 1] and src[1].tolist() == [2, -1, -1]
+    assert np.all(fb[1, 1:] == 0) and np.all(fs[1, 1:] == 0)
+
+
+# ----------------------------------------------------------------------------- NMS
+def _nms(boxes, scores, **kw):
+    args = dict(max_output_size_per_class=32, max_total_size=32, iou_threshold=0.45, score_threshold=0.25)
+    args.update(kw)
+    b = np.asarray(boxes, F)[None]
+    s = np.asarray(scores, F)[None]
+    a = P.combined_nms(b, s, **args)
+    c = cref.combined_nms(b, s, **args)
+    for x, y in zip(a, c):
+        np.testing.assert_array_equal(x, y)
+    return a
+
+
+def test_nms_identical_boxes_keep_first():
+    ob, os_, oc, ov, ok = _nms([[0, 0, .5, .5]] * 3, [[.9], [.8], [.7]])
+    assert ov[0] == 1 and ok[0, 0] == 0 and ok[0, 1] == -1 and os_[0, 0] == F(0.9)
+
+
+def test_nms_iou_exactly_at_threshold_is_kept():
+    # A = 0.5 x 1.0, B = 0.5 x 0.5 inside A: inter 0.25, union 0.5, IoU = 0.5 exactly
+    boxes = [[0, 0, .5, 1.0], [0, 0, .5, .5]]
+    assert P.nms_iou(np.array(boxes[0], F), np.array([boxes[1]], F))[0] == F(0.5)
+    _, _, _, ov, ok = _nms(boxes, [[.9], [.8]], iou_threshold=0.5)
+    assert ov[0] == 2 and ok[0, :2].tolist() == [0, 1]
+    _, _, _, ov, _ = _nms(boxes, [[.9], [.8]], iou_threshold=0.49)
+    assert ov[0] == 1
+
+
+def test_nms_score_threshold_is_strict():
+    _, _, _, ov, ok = _nms([[0, 0, .1, .1], [.5, .5, .6, .6]], [[.25], [.26]], score_threshold=0.25)
+    assert ov[0] == 1 and ok[0, 0] == 1
+
+
+def test_nms_ties_break_by_index_then_class():
+    boxes = [[0, 0, .1, .1], [.5, .5, .6, .6], [.8, .8, .9, .9]]
+    # same score everywhere: per class index order; merged by class asc then index asc
+    scores = [[.5, .5], [.5, .5], [.5, .5]]
+    _, _, oc, ov, ok = _nms(boxes, scores)
+    assert ov[0] == 6
+    assert oc[0, :6].tolist() == [0, 0, 0, 1, 1, 1] and ok[0, :6].tolist() == [0, 1, 2, 0, 1, 2]
+    # within a class a tie is won by the lower index: box 1 overlaps box 0 and loses
+    boxes = [[0, 0, .5, .5], [0, 0, .5, .45], [.6, .6, .9, .9]]
+    _, _, _, ov, ok = _nms(boxes, [[.7], [.7], [.7]])
+    assert ok[0, :2].tolist() == [0, 2] and ov[0] == 2
+
+
+def test_nms_zero_area_and_flipped_boxes():
+    # zero-area boxes never overlap anything; flipped corners are normalised for IoU only
+    boxes = [[.2, .2, .2, .6], [.2, .2, .2, .6], [.5, .5, 0, 0], [0, 0, .5, .5]]
+    ob, _, _, ov, ok = _nms(boxes, [[.9], [.8], [.7], [.6]])
+    assert ov[0] == 3 and ok[0, :3].tolist() == [0, 1, 2]      # box 3 == box 2 flipped -> suppressed
+    np.testing.assert_array_equal(ob[0, 2], np.array([.5, .5, 0, 0], F))   # emitted as given (clipped)
+
+
+def test_nms_clips_and_caps():
+    boxes = [[-.2, -.1, .3, 1.4]] + [[.1 * i, .1 * i, .1 * i + .05, .1 * i + .05] for i in range(1, 9)]
+    scores = [[.95]] + [[.9 - .01 * i] for i in range(1, 9)]
+    ob, os_, _, ov, ok = _nms(boxes, scores, max_output_size_per_class=5, max_total_size=3)
+    assert ov[0] == 3 and ok[0].tolist() == [0, 1, 2]
+    np.testing.assert_allclose(ob[0, 0], [0, 0, .3, 1.0])
+    _, _, _, ov, _ = _nms(boxes, scores, max_output_size_per_class=2, max_total_size=8)
+    assert ov[0] == 2
+
+
+def test_nms_counts_and_src_idx():
+    rng = np.random.default_rng(3)
+    boxes = rng.random((2, 20, 4)).astype(F)
+    scores = rng.random((2, 20, 3)).astype(F)
+    counts = np.array([20, 7], np.int32)
+    src = np.arange(40, dtype=np.int32).reshape(2, 20) * 3
+    a = P.combined_nms(boxes, scores, counts, 4, 6, 0.3, 0.2, src_idx=src)
+    c = cref.combined_nms(boxes, scores, counts, 4, 6, 0.3, 0.2, src_idx=src)
+    for x, y in zip(a, c):
+        np.testing.assert_array_equal(x, y)
+    assert np.all(a[4][1][a[4][1] >= 0] < 60 + 7 * 3)          # image 1 only uses its first 7
+    empty = P.combined_nms(boxes, scores, np.zeros(2, np.int32), 4, 6, 0.3, 0.2)
+    assert empty[3].tolist() == [0, 0] and np.all(empty[4] == -1) and np.all(empty[0] == 0)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_numpy_and_c_restatements_agree(seed):
+    rng = np.random.default_rng(seed)
+    C = [5, 80, 1][seed]
+    heads = [rng.normal(0, 2, (2, S, S, 3, 5 + C)).astype(F) for S in (8, 4, 2)]
+    b1, s1 = P.decode_all(heads, C)
+    b2, s2 = cref.decode_all(heads, C)
+    np.testing.assert_allclose(b1, b2, rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(s1, s2, rtol=2e-6, atol=1e-7)
+    f1 = P.filter_bboxes(b1, s1, 0.25, 64)
+    f2 = cref.filter_bboxes(b1, s1, 0.25, 64)
+    for x, y in zip(f1, f2):
+        np.testing.assert_array_equal(x, y)
+    n1 = P.combined_nms(f1[0], f1[1], f1[2], 8, 16, 0.45, 0.25, src_idx=f1[3])
+    n2 = cref.combined_nms(f1[0], f1[1], f1[2], 8, 16, 0.45, 0.25, src_idx=f1[3])
+    for x, y in zip(n1, n2):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_bbox_iou_known_answers():
+    a = np.array([[5, 5, 10, 10]], F)          # [0,10]^2
+    b = np.array([[10, 5, 10, 10]], F)         # x in [5,15]: inter 50, union 150
+    np.testing.assert_allclose(P.bbox_iou(a, b), [1 / 3], rtol=1e-6)
+    np.testing.assert_allclose(P.bbox_giou(a, b), [1 / 3 - 0.0], rtol=1e-6)   # enclosing box == union hull
+    z = np.zeros((1, 4), F)
+    assert P.bbox_iou(z, z)[0] == 0 and P.bbox_giou(z, z)[0] == 0             # divide_no_nan
+    c = np.array([[30, 5, 10, 10]], F)         # disjoint: iou 0, hull 35x10, union 200 -> giou = -(350-200)/350
+    np.testing.assert_allclose(P.bbox_giou(a, c), [-150 / 350], rtol=1e-6)
+    assert P.bbox_iou(a[:, None], np.stack([b[0], c[0]])[None]).shape == (1, 2)
+
+
+# ----------------------------------------------------------------------------- conv net
+def test_conv_padding_semantics():
+    """stride 1 = SAME; downsample = one zero row/col on top/left, VALID, stride 2 (layers.py:46-57)."""
+    x = torch.arange(16, dtype=torch.float32).reshape(1, 4, 4, 1)
+    p = {"kernel": torch.ones(3, 3, 1, 1), "bias": torch.zeros(1)}
+    y = N.yolo_conv(x, p, False, None)
+    assert y.shape == (1, 4, 4, 1)
+    assert y[0, 0, 0, 0] == 0 + 1 + 4 + 5 and y[0, 3, 3, 0] == 10 + 11 + 14 + 15
+    y = N.yolo_conv(x, p, True, None)
+    assert y.shape == (1, 2, 2, 1)
+    # output (0,0) covers rows/cols -1..1 of x -> x[0:2,0:2]; output (1,1) covers rows/cols 1..3
+    assert y[0, 0, 0, 0] == 0 + 1 + 4 + 5
+    assert y[0, 1, 1, 0] == sum(float(x[0, r, c, 0]) for r in (1, 2, 3) for c in (1, 2, 3))
+
+
+def test_activations_and_bn():
+    v = torch.tensor([-30.0, -1.0, 0.0, 1.0, 30.0])
+    m = N.mish(v)
+    np.testing.assert_allclose(m[3].item(), 1.0 * math.tanh(math.log1p(math.e)), rtol=1e-6)
+    assert abs(m[0].item()) < 1e-10 and m[4].item() == 30.0
+    np.testing.assert_allclose(N.activation(v, "leaky").numpy(), [-3.0, -0.1, 0.0, 1.0, 30.0], rtol=1e-6)
+    with pytest.raises(ValueError):
+        N.activation(v, "relu")
+    x = torch.ones(1, 1, 1, 2)
+    p = {"kernel": torch.ones(1, 1, 2, 1), "gamma": torch.tensor([2.0]), "beta": torch.tensor([0.5]),
+         "mean": torch.tensor([1.0]), "var": torch.tensor([4.0 - 1e-3])}
+    y = N.yolo_conv(x, p, False, None)          # conv = 2 ; (2-1)/sqrt(4)*2 + 0.5 = 1.5
+    np.testing.assert_allclose(y.item(), 1.5, rtol=1e-6)
+
+
+def test_upsample_half_pixel():
+    x = torch.tensor([0.0, 4.0]).reshape(1, 1, 2, 1)
+    y = N.upsample2x(x)
+    np.testing.assert_allclose(y[0, :, :, 0].numpy(), [[0, 1, 3, 4], [0, 1, 3, 4]], rtol=1e-6)
+
+
+def test_network_shapes_and_sizes():
+    specs = N.darknet53_specs() + N.yolov3_specs(80)
+    assert len(N.darknet53_specs()) == 52 and len(N.yolov3_specs(80)) == 21
+    assert sum(k * k * ci * co + co for k, ci, co, _, _ in specs) == 88419869
+    bp = N.init_params(N.darknet53_specs(), seed=0)
+    hp = N.init_params(N.yolov3_specs(2), seed=1)
+    x = torch.rand(1, 64, 64, 3, generator=torch.Generator().manual_seed(1))
+    s1, s2, s3 = N.darknet53_forward(bp, x)
+    assert s1.shape == (1, 8, 8, 256) and s2.shape == (1, 4, 4, 512) and s3.shape == (1, 2, 2, 1024)
+    s, m, l = N.yolov3_forward(hp, s1, s2, s3, 2)
+    assert s.shape == (1, 8, 8, 21) and m.shape == (1, 4, 4, 21) and l.shape == (1, 2, 2, 21)
+
+
+# ----------------------------------------------------------------------------- goldens
+def test_postproc_goldens(golden_dir):
+    files = sorted(glob.glob(os.path.join(golden_dir, "postproc_*.npz")))
+    assert len(files) == 3
+    for f in files:
+        g = np.load(f)
+        C = int(g["C"])
+        heads = [g["head%d" % i] for i in range(3)]
+        for impl in (P, cref):
+            xywh, sc = impl.decode_all(heads, C)
+            np.testing.assert_allclose(xywh, g["xywh"], rtol=3e-6, atol=1e-6)
+            np.testing.assert_allclose(sc, g["scores"], rtol=3e-6, atol=1e-7)
+            fb, fs, counts, src = impl.filter_bboxes(g["xywh"], g["scores"], float(g["thr"]), float(g["image_size"]))
+            np.testing.assert_array_equal(counts, g["f_counts"])
+            np.testing.assert_array_equal(src, g["f_src"])
+            np.testing.assert_array_equal(fb, g["f_boxes"])
+            np.testing.assert_array_equal(fs, g["f_scores"])
+            out = impl.combined_nms(g["f_boxes"], g["f_scores"], g["f_counts"], int(g["per_class"]),
+                                    int(g["total"]), float(g["iou"]), float(g["thr"]), src_idx=g["f_src"])
+            for got, key in zip(out, ("n_boxes", "n_scores", "n_classes", "n_valid", "n_keep")):
+                np.testing.assert_array_equal(got, g[key])
+
+
+def test_nms_goldens(golden_dir):
+    for name in ("nms_dense", "nms_ties"):
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        for impl in (P, cref):
+            out = impl.combined_nms(g["boxes"], g["scores"], g["counts"], int(g["per_class"]), int(g["total"]),
+                                    float(g["iou"]), float(g["thr"]))
+            for got, key in zip(out, ("n_boxes", "n_scores", "n_classes", "n_valid", "n_keep")):
+                np.testing.assert_array_equal(got, g[key])
+        assert g["n_valid"].min() > 0
+
+
+def test_conv_goldens(golden_dir):
+    files = sorted(glob.glob(os.path.join(golden_dir, "conv_*.npz")))
+    assert len(files) == 5
+    for f in files:
+        g = np.load(f)
+        p = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("p_")}
+        act = str(g["act"])
+        y = N.yolo_conv(torch.from_numpy(g["x"]), p, bool(g["down"]), None if act == "none" else act)
+        if "residual" in g.files:
+            y = y + torch.from_numpy(g["residual"])
+        np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-4, atol=1e-5)

@@ -1,0 +1,106 @@
+"""ctypes binding of libymx.so (the HIP kernels behind the C ABI in include/ymx.h).
+
+There is no CPU fallback: a missing library or a non-GPU tensor raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libymx.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_LEAKY, ACT_MISH = 0, 1, 2
+ACT_CODES = {None: ACT_NONE, "leaky": ACT_LEAKY, "mish": ACT_MISH}
+
+_vp, _i, _f, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_longlong
+
+
+class ymx_op(ctypes.Structure):
+    """Mirror of ``struct ymx_op`` in include/ymx.h."""
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("kind", "B", "H", "W", "Cin", "Cout", "k", "stride", "act", "dtype", "x_dtype",
+                 "out_dtype", "x_ld", "res_ld", "y_ld", "C1", "C2")] + \
+               [(n, ctypes.c_void_p) for n in ("x", "w", "scale", "shift", "residual", "y")]
+
+
+# name -> (restype, argtypes); every symbol include/ymx.h declares
+SIGNATURES = {
+    "ymx_version": (_i, []),
+    "ymx_last_error": (ctypes.c_char_p, []),
+    "ymx_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
+    "ymx_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "ymx_conv2d_fused": (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
+    "ymx_conv2d_fused_ex": (_i, [_vp] * 6 + [_i] * 14 + [_vp]),
+    "ymx_upsample2x_concat": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ymx_run_program": (_i, [ctypes.POINTER(ymx_op), _i, _vp]),
+    "ymx_decode_workspace_bytes": (_sz, [_i, _i, ctypes.POINTER(_i)]),
+    "ymx_decode_filter": (_i, [ctypes.POINTER(_vp), _i, ctypes.POINTER(_i), _i, _i, _i,
+                               ctypes.POINTER(_f), ctypes.POINTER(_f), ctypes.POINTER(_f),
+                               _i, _f, _f, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "ymx_decode_split": (_i, [ctypes.POINTER(_vp), _i, ctypes.POINTER(_i), _i, _i, _i,
+                              ctypes.POINTER(_f), ctypes.POINTER(_f), ctypes.POINTER(_f),
+                              _vp, _vp, _vp, _vp, _i, _vp]),
+    "ymx_filter_workspace_bytes": (_sz, [_i, _i]),
+    "ymx_filter_boxes": (_i, [_vp, _vp, _ll, _ll, _ll, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _i,
+                              _vp, _sz, _vp]),
+    "ymx_nms_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ymx_nms_combined": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _sz, _vp]),
+    "ymx_affine_act": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
+    "ymx_bbox_iou": (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "yolo_amd: %s is missing - build it with `make -C yolo_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    """Turn a negative ymx return code into the matching Python exception."""
+    if rc == 0:
+        return
+    msg = lib().ymx_last_error().decode("utf-8", "replace")
+    if rc in (-1, -2):
+        raise ValueError("ymx: " + msg)
+    raise RuntimeError("ymx (%d): %s" % (rc, msg))
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise ValueError("yolo_amd supports float32 and bfloat16 tensors, got %s" % dt)
+
+
+def require_gpu(*tensors):
+    """Product ops run on the GPU only; anything else is an error, not a fallback."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("yolo_amd: tensor on %s; the HIP path needs a GPU tensor "
+                               "(there is no CPU fallback)" % t.device)
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

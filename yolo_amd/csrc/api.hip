@@ -1,0 +1,301 @@
+// extern "C" surface of libymx: argument validation, kernel selection, error strings.
+// No device memory is allocated or freed here and nothing synchronises; the only
+// runtime calls besides launches are hipMemsetAsync on caller-provided workspace.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "common.h"
+
+namespace ymx {
+
+static thread_local std::string g_err;
+static thread_local float *g_split_conf = nullptr;   // set only inside ymx_decode_split
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+int check_launch(const char *what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(YMX_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return YMX_OK;
+}
+
+static bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+static int conv_impl(const void *x, const void *w, const void *scale, const void *shift,
+                     const void *residual, void *y, int B, int H, int W, int Cin, int Cout, int k,
+                     int stride, int act, int dtype, int x_dtype, int out_dtype, int x_ld, int res_ld,
+                     int y_ld, hipStream_t s) {
+    if (!x || !w || !y) return fail(YMX_EARG, "conv2d: null x, w or y");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(YMX_EARG, "conv2d: non-positive size");
+    if (k < 1 || k > 5 || (k & 1) == 0) return fail(YMX_EUNSUPPORTED, "conv2d: kernel size %d (odd, <= 5)", k);
+    if (stride != 1 && stride != 2) return fail(YMX_EUNSUPPORTED, "conv2d: stride %d (1 or 2)", stride);
+    if (act != YMX_ACT_NONE && act != YMX_ACT_LEAKY && act != YMX_ACT_MISH)
+        return fail(YMX_EARG, "conv2d: activation code %d", act);
+    if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "conv2d: dtype %d", dtype);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = w; a.res = residual; a.y = y;
+    a.scale = (const float *)scale; a.shift = (const float *)shift;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.k = k; a.stride = stride;
+    if (stride == 1) {
+        a.pad = (k - 1) / 2; a.OH = H; a.OW = W;                   // SAME
+    } else {
+        a.pad = 1;                                                 // top/left only, then VALID
+        if (H + 1 < k || W + 1 < k) return fail(YMX_EARG, "conv2d: input smaller than kernel");
+        a.OH = (H + 1 - k) / 2 + 1; a.OW = (W + 1 - k) / 2 + 1;
+    }
+    a.x_ld = x_ld > 0 ? x_ld : Cin;
+    a.res_ld = res_ld > 0 ? res_ld : Cout;
+    a.y_ld = y_ld > 0 ? y_ld : Cout;
+    if (a.x_ld < Cin || a.y_ld < Cout || a.res_ld < Cout) return fail(YMX_EARG, "conv2d: pixel stride below channel count");
+    const long long P = (long long)B * a.OH * a.OW;
+    if (P > 0x7fffffffLL || (long long)B * H * W * a.x_ld > 0x7fffffffLL || P * a.y_ld > 0x7fffffffffLL)
+        return fail(YMX_EUNSUPPORTED, "conv2d: tensor exceeds 2^31 elements");
+    a.P = (int)P;
+    a.K = k * k * Cin;
+    a.act = act;
+    a.dtype = dtype; a.x_dtype = x_dtype; a.out_dtype = out_dtype;
+    if (conv_uses_mfma(Cin, dtype)) {
+        if (x_dtype != dtype) return fail(YMX_EUNSUPPORTED, "conv2d: MFMA path needs x_dtype == dtype");
+        const int kch = dtype == YMX_BF16 ? 8 : 4;
+        if (a.x_ld % kch) return fail(YMX_EARG, "conv2d: x pixel stride %d not a multiple of %d", a.x_ld, kch);
+        if (!aligned16(x) || !aligned16(w)) return fail(YMX_EARG, "conv2d: x and w must be 16-byte aligned");
+        if (!aligned16(y) || (residual && !aligned16(residual))) return fail(YMX_EARG, "conv2d: y/residual must be 16-byte aligned");
+        a.Kw = packed_kw(k, Cin);
+        return launch_conv_igemm(a, s);
+    }
+    if (!aligned16(y)) return fail(YMX_EARG, "conv2d: y must be 16-byte aligned");
+    a.Kw = Cout;
+    return launch_conv_direct(a, s);
+}
+
+}  // namespace ymx
+
+using namespace ymx;
+
+extern "C" {
+
+int ymx_version(void) { return YMX_VERSION; }
+const char *ymx_last_error(void) { return g_err.c_str(); }
+
+size_t ymx_packed_weight_bytes(int k, int Cin, int Cout, int dtype) {
+    if (k <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    if (!conv_uses_mfma(Cin, dtype)) return (size_t)k * k * Cin * Cout * 4;
+    return (size_t)packed_rows(Cout) * packed_kw(k, Cin) * (dtype == YMX_BF16 ? 2 : 4);
+}
+
+int ymx_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype, void *stream) {
+    if (!w_hwio || !w_packed) return fail(YMX_EARG, "pack_weights: null pointer");
+    if (k <= 0 || Cin <= 0 || Cout <= 0) return fail(YMX_EARG, "pack_weights: non-positive size");
+    if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "pack_weights: dtype %d", dtype);
+    return launch_pack_weights(w_hwio, w_packed, k, Cin, Cout, dtype, (hipStream_t)stream);
+}
+
+int ymx_conv2d_fused(const void *x, const void *w, const void *scale, const void *shift, const void *residual,
+                     void *y, int B, int H, int W, int Cin, int Cout, int k, int stride, int act, int dtype,
+                     void *stream) {
+    return conv_impl(x, w, scale, shift, residual, y, B, H, W, Cin, Cout, k, stride, act, dtype, dtype, dtype, 0,
+                     0, 0, (hipStream_t)stream);
+}
+
+int ymx_conv2d_fused_ex(const void *x, const void *w, const void *scale, const void *shift, const void *residual,
+                        void *y, int B, int H, int W, int Cin, int Cout, int k, int stride, int act, int dtype,
+                        int x_dtype, int out_dtype, int x_ld, int res_ld, int y_ld, void *stream) {
+    if ((x_dtype != YMX_F32 && x_dtype != YMX_BF16) || (out_dtype != YMX_F32 && out_dtype != YMX_BF16))
+        return fail(YMX_EARG, "conv2d: x_dtype %d / out_dtype %d", x_dtype, out_dtype);
+    return conv_impl(x, w, scale, shift, residual, y, B, H, W, Cin, Cout, k, stride, act, dtype, x_dtype, out_dtype,
+                     x_ld, res_ld, y_ld, (hipStream_t)stream);
+}
+
+int ymx_upsample2x_concat(const void *skip, const void *x, void *y, int B, int H, int W, int C1, int C2, int dtype,
+                          void *stream) {
+    if (!x || !y || (C1 > 0 && !skip)) return fail(YMX_EARG, "upsample2x_concat: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C1 < 0 || C2 <= 0) return fail(YMX_EARG, "upsample2x_concat: bad size");
+    if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "upsample2x_concat: dtype %d", dtype);
+    const int kch = dtype == YMX_BF16 ? 8 : 4;
+    if (C1 % kch || C2 % kch) return fail(YMX_EUNSUPPORTED, "upsample2x_concat: channels must be multiples of %d", kch);
+    if (!aligned16(x) || !aligned16(y) || (skip && !aligned16(skip))) return fail(YMX_EARG, "upsample2x_concat: 16-byte alignment");
+    return launch_upsample2x_concat(skip, x, y, B, H, W, C1, C2, dtype, (hipStream_t)stream);
+}
+
+int ymx_run_program(const ymx_op *ops, int n_ops, void *stream) {
+    if (!ops || n_ops < 0) return fail(YMX_EARG, "run_program: bad program");
+    for (int i = 0; i < n_ops; ++i) {
+        const ymx_op &o = ops[i];
+        int rc;
+        if (o.kind == 1)
+            rc = conv_impl(o.x, o.w, o.scale, o.shift, o.residual, o.y, o.B, o.H, o.W, o.Cin, o.Cout, o.k, o.stride,
+                           o.act, o.dtype, o.x_dtype, o.out_dtype, o.x_ld, o.res_ld, o.y_ld, (hipStream_t)stream);
+        else if (o.kind == 2)
+            rc = ymx_upsample2x_concat(o.residual, o.x, o.y, o.B, o.H, o.W, o.C1, o.C2, o.dtype, stream);
+        else
+            rc = fail(YMX_EARG, "run_program: op %d has unknown kind %d", i, o.kind);
+        if (rc != YMX_OK) {
+            const std::string inner = g_err;
+            return fail(rc, "run_program: op %d: %s", i, inner.c_str());
+        }
+    }
+    return YMX_OK;
+}
+
+// workspace layout of the decode/filter calls: [err:4 int][ticket: B int, padded to 16 B][state: B*nseg u64]
+static size_t decode_ws_bytes(int B, int nseg) {
+    const size_t head = ((size_t)(4 + B) * 4 + 15) & ~(size_t)15;
+    return head + (size_t)B * nseg * 8;
+}
+static int count_segments(int n_scales, const int *S) {
+    int n = 0;
+    for (int i = 0; i < n_scales; ++i) n += (3 * S[i] * S[i] + 255) / 256;
+    return n;
+}
+
+size_t ymx_decode_workspace_bytes(int B, int n_scales, const int *S) {
+    if (B <= 0 || n_scales <= 0 || n_scales > 3 || !S) return 0;
+    return decode_ws_bytes(B, count_segments(n_scales, S));
+}
+
+static int setup_ws(DecodeArgs &a, void *workspace, size_t ws_bytes, hipStream_t s) {
+    const size_t need = decode_ws_bytes(a.B, a.nseg);
+    if (!workspace || ws_bytes < need) return fail(YMX_EWORKSPACE, "decode: workspace %zu < %zu bytes", ws_bytes, need);
+    if (!aligned16(workspace)) return fail(YMX_EARG, "decode: workspace must be 16-byte aligned");
+    const size_t head = ((size_t)(4 + a.B) * 4 + 15) & ~(size_t)15;
+    a.err = (int *)workspace;
+    a.ticket = (int *)workspace + 4;
+    a.state = (unsigned long long *)((char *)workspace + head);
+    if (hipMemsetAsync(workspace, 0, need, s) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(YMX_ELAUNCH, "decode: hipMemsetAsync failed");
+    }
+    return YMX_OK;
+}
+
+int ymx_decode_filter(const void *const *head, int n_scales, const int *S, int B, int C, int head_dtype,
+                      const float *anchors, const float *strides, const float *xyscale, int filter, float thr,
+                      float image_size, float *boxes, float *scores, int *src_idx, int *counts, int cap,
+                      void *workspace, size_t ws_bytes, void *stream) {
+    if (!head || !S || !anchors || !strides || !xyscale || !boxes || !scores || !counts)
+        return fail(YMX_EARG, "decode_filter: null pointer");
+    if (n_scales < 1 || n_scales > 3) return fail(YMX_EUNSUPPORTED, "decode_filter: 1..3 scales, got %d", n_scales);
+    if (B <= 0 || C <= 0 || cap <= 0 || (cap & 3)) return fail(YMX_EARG, "decode_filter: bad B/C/cap (cap %% 4 == 0)");
+    if (filter && !src_idx) return fail(YMX_EARG, "decode_filter: src_idx required when filtering");
+    if (!aligned16(boxes) || !aligned16(scores)) return fail(YMX_EARG, "decode_filter: boxes/scores must be 16-byte aligned");
+    DecodeArgs a;
+    memset(&a, 0, sizeof(a));
+    int nseg = 0, ncand = 0;
+    for (int i = 0; i < n_scales; ++i) {
+        if (!head[i] || S[i] <= 0) return fail(YMX_EARG, "decode_filter: scale %d missing", i);
+        a.head[i] = head[i]; a.S[i] = S[i];
+        a.seg_begin[i] = nseg; a.cand_begin[i] = ncand;
+        nseg += (3 * S[i] * S[i] + 255) / 256; ncand += 3 * S[i] * S[i];
+        a.stride[i] = strides[i]; a.xyscale[i] = xyscale[i];
+        for (int j = 0; j < 6; ++j) (&a.anchor[i][0][0])[j] = anchors[i * 6 + j];
+    }
+    a.seg_begin[n_scales] = nseg; a.cand_begin[n_scales] = ncand;
+    a.n_scales = n_scales; a.B = B; a.C = C; a.N = ncand; a.cap = cap; a.head_dtype = head_dtype;
+    a.filter = filter ? 1 : 0; a.thr = thr; a.image_size = image_size;
+    a.boxes = boxes; a.scores = scores; a.src_idx = src_idx; a.counts = counts; a.nseg = nseg;
+    a.conf = filter ? nullptr : g_split_conf;
+    if (!filter && cap < ncand) return fail(YMX_EARG, "decode_filter: cap %d < %d candidates", cap, ncand);
+    if (filter) {
+        const int rc = setup_ws(a, workspace, ws_bytes, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return launch_decode(a, (hipStream_t)stream);
+}
+
+int ymx_decode_split(const void *const *head, int n_scales, const int *S, int B, int C, int head_dtype,
+                     const float *anchors, const float *strides, const float *xyscale, float *boxes, float *conf,
+                     float *prob, int *counts, int cap, void *stream) {
+    if (!conf) return fail(YMX_EARG, "decode_split: null conf");
+    g_split_conf = conf;
+    const int rc = ymx_decode_filter(head, n_scales, S, B, C, head_dtype, anchors, strides, xyscale, 0, 0.0f, 1.0f, boxes,
+                                     prob, nullptr, counts, cap, nullptr, 0, stream);
+    g_split_conf = nullptr;
+    return rc;
+}
+
+size_t ymx_filter_workspace_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return decode_ws_bytes(B, (N + 255) / 256);
+}
+
+int ymx_filter_boxes(const float *xywh, const float *scores, long long sb, long long sn, long long sc, int B, int N,
+                     int C, float thr, float image_size, float *boxes, float *out_scores, int *src_idx, int *counts,
+                     int cap, void *workspace, size_t ws_bytes, void *stream) {
+    if (!xywh || !scores || !boxes || !out_scores || !src_idx || !counts) return fail(YMX_EARG, "filter_boxes: null pointer");
+    if (B <= 0 || N <= 0 || C <= 0 || cap <= 0 || (cap & 3)) return fail(YMX_EARG, "filter_boxes: bad B/N/C/cap");
+    if (sb < 0 || sn < 0 || sc < 0) return fail(YMX_EUNSUPPORTED, "filter_boxes: negative strides");
+    if (!aligned16(xywh) || !aligned16(boxes) || !aligned16(out_scores)) return fail(YMX_EARG, "filter_boxes: 16-byte alignment");
+    DecodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_scales = 1; a.S[0] = 1; a.seg_begin[0] = 0; a.cand_begin[0] = 0;
+    a.nseg = (N + 255) / 256; a.seg_begin[1] = a.nseg; a.cand_begin[1] = N;
+    a.B = B; a.C = C; a.N = N; a.cap = cap; a.filter = 2; a.thr = thr; a.image_size = image_size;
+    a.in_xywh = xywh; a.in_scores = scores; a.sb = sb; a.sn = sn; a.sc = sc;
+    a.boxes = boxes; a.scores = out_scores; a.src_idx = src_idx; a.counts = counts;
+    const int rc = setup_ws(a, workspace, ws_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_decode(a, (hipStream_t)stream);
+}
+
+size_t ymx_nms_workspace_bytes(int B, int C, int per_class) {
+    if (B <= 0 || C <= 0 || per_class <= 0) return 0;
+    return (size_t)B * C * per_class * 8 + (((size_t)B * C * 4 + 15) & ~(size_t)15);
+}
+
+int ymx_nms_combined(const float *boxes, const float *scores, const int *counts, const int *src_idx, int B, int cap,
+                     int C, int per_class, int total, float iou_thr, float score_thr, float *out_boxes,
+                     float *out_scores, float *out_classes, int *out_valid, int *out_keep_idx, void *workspace,
+                     size_t ws_bytes, void *stream) {
+    if (!boxes || !scores || !out_boxes || !out_scores || !out_classes || !out_valid || !out_keep_idx)
+        return fail(YMX_EARG, "nms_combined: null pointer");
+    if (B <= 0 || cap <= 0 || C <= 0 || per_class <= 0 || total <= 0) return fail(YMX_EARG, "nms_combined: non-positive size");
+    if (cap & 3) return fail(YMX_EARG, "nms_combined: cap %d must be a multiple of 4", cap);
+    if (per_class > 64 || C > 2048 || (long long)C * per_class > 8192 || cap > (1 << 21))
+        return fail(YMX_EUNSUPPORTED, "nms_combined: limits per_class<=64, C<=2048, C*per_class<=8192, cap<=2097152");
+    if (!aligned16(boxes) || !aligned16(scores) || !aligned16(out_boxes)) return fail(YMX_EARG, "nms_combined: 16-byte alignment");
+    const size_t need = ymx_nms_workspace_bytes(B, C, per_class);
+    if (!workspace || ws_bytes < need) return fail(YMX_EWORKSPACE, "nms_combined: workspace %zu < %zu bytes", ws_bytes, need);
+    if (!aligned16(workspace)) return fail(YMX_EARG, "nms_combined: workspace must be 16-byte aligned");
+    NmsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.boxes = boxes; a.scores = scores; a.counts = counts; a.src_idx = src_idx;
+    a.B = B; a.cap = cap; a.C = C; a.per_class = per_class; a.total = total;
+    a.iou_thr = iou_thr; a.score_thr = score_thr;
+    a.out_boxes = out_boxes; a.out_scores = out_scores; a.out_classes = out_classes;
+    a.out_valid = out_valid; a.out_keep = out_keep_idx;
+    a.kept_keys = (unsigned long long *)workspace;
+    a.kept_cnt = (int *)((char *)workspace + (size_t)B * C * per_class * 8);
+    return launch_nms(a, (hipStream_t)stream);
+}
+
+int ymx_affine_act(const void *x, const float *scale, const float *shift, void *y, long long n_pix, int C, int act,
+                   int dtype, void *stream) {
+    if (!x || !y) return fail(YMX_EARG, "affine_act: null pointer");
+    if (n_pix < 0 || C <= 0) return fail(YMX_EARG, "affine_act: bad size");
+    if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "affine_act: dtype %d", dtype);
+    if (act != YMX_ACT_NONE && act != YMX_ACT_LEAKY && act != YMX_ACT_MISH) return fail(YMX_EARG, "affine_act: activation code %d", act);
+    if (n_pix == 0) return YMX_OK;
+    return launch_affine_act(x, scale, shift, y, n_pix * C, C, act, dtype, (hipStream_t)stream);
+}
+
+int ymx_bbox_iou(const float *b1, const float *b2, float *out, long long n, int giou, void *stream) {
+    if (!b1 || !b2 || !out) return fail(YMX_EARG, "bbox_iou: null pointer");
+    if (n < 0) return fail(YMX_EARG, "bbox_iou: negative count");
+    if (n == 0) return YMX_OK;
+    if (!aligned16(b1) || !aligned16(b2)) return fail(YMX_EARG, "bbox_iou: boxes must be 16-byte aligned");
+    return launch_bbox_iou(b1, b2, out, n, giou, (hipStream_t)stream);
+}
+
+}  // extern "C"

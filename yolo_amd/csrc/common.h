@@ -1,0 +1,127 @@
+// Internal declarations shared by the kernel translation units and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/ymx.h"
+
+namespace ymx {
+
+// ---- error reporting (thread-local message behind ymx_last_error) ------------
+int fail(int code, const char *fmt, ...);
+int check_launch(const char *what);
+
+// ---- element helpers ---------------------------------------------------------
+typedef uint16_t bf16_t;   // raw bfloat16 bits in memory
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// Round to nearest even; the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and
+// keeps NaN a NaN.
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct elem;
+template <> struct elem<float> {
+    static constexpr int code = YMX_F32;
+    __device__ static __forceinline__ float load(const float *p) { return *p; }
+    __device__ static __forceinline__ void store(float *p, float v) { *p = v; }
+};
+template <> struct elem<bf16_t> {
+    static constexpr int code = YMX_BF16;
+    __device__ static __forceinline__ float load(const bf16_t *p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void store(bf16_t *p, float v) { *p = f32_to_bf16(v); }
+};
+
+// Workgroups are dealt round-robin over the 8 XCDs, so ids b and b+8 share an L2.
+// Give every XCD one contiguous run of logical tile ids (bijective for any grid).
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// x * tanh(softplus(x)) with one exp:  tanh(log(1+e)) = (e^2+2e)/(e^2+2e+2).
+__device__ __forceinline__ float mish_f(float x) {
+    const float e = __expf(fminf(x, 20.0f));
+    const float n = e * (e + 2.0f);
+    const float m = x * (n / (n + 2.0f));
+    return x > 20.0f ? x : m;
+}
+__device__ __forceinline__ float act_f(float v, int act) {
+    if (act == YMX_ACT_MISH) return mish_f(v);
+    if (act == YMX_ACT_LEAKY) return v > 0.0f ? v : 0.1f * v;
+    return v;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ---- launchers (one per kernel family; defined next to the kernels) -----------
+struct ConvArgs {
+    const void *x, *w, *res;
+    const float *scale, *shift;
+    void *y;
+    int B, H, W, Cin, Cout, OH, OW;
+    int k, stride, pad;
+    int x_ld, res_ld, y_ld;      // pixel strides in elements
+    int P;                       // B*OH*OW output pixels
+    int K;                       // k*k*Cin
+    int Kw;                      // row stride of the packed weights (elements)
+    int act;
+    int dtype, x_dtype, out_dtype;
+};
+
+// Packed weight geometry, shared by pack and conv.
+static inline bool conv_uses_mfma(int Cin, int dtype) {
+    return dtype == YMX_BF16 ? (Cin % 8 == 0) : (Cin % 4 == 0);
+}
+static inline int packed_kw(int k, int Cin) { return ((k * k * Cin + 63) / 64) * 64; }
+static inline int packed_rows(int Cout) { return ((Cout + 127) / 128) * 128; }
+
+int launch_conv_igemm(const ConvArgs &a, hipStream_t s);
+int launch_conv_direct(const ConvArgs &a, hipStream_t s);
+int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype,
+                        hipStream_t s);
+int launch_upsample2x_concat(const void *skip, const void *x, void *y, int B, int H, int W, int C1,
+                             int C2, int dtype, hipStream_t s);
+int launch_affine_act(const void *x, const float *scale, const float *shift, void *y, long long n, int C, int act,
+                      int dtype, hipStream_t s);
+int launch_bbox_iou(const float *b1, const float *b2, float *out, long long n, int giou,
+                    hipStream_t s);
+
+struct DecodeArgs {
+    const void *head[3];
+    int S[3];
+    int seg_begin[4];            // first segment of each scale (segments of 256 candidates)
+    int cand_begin[4];           // first candidate of each scale in the concatenated list
+    float stride[3], xyscale[3], anchor[3][3][2];
+    int n_scales, B, C, N, cap, head_dtype;
+    int filter;                  // 0: decode only, 1: decode+filter, 2: filter decoded input
+    float thr, image_size;
+    const float *in_xywh, *in_scores;    // filter == 2
+    long long sb, sn, sc;
+    float *boxes, *scores;
+    float *conf;                 // filter == 0 only: if set, scores = class prob alone and conf[b][n] = objectness
+    int *src_idx, *counts;
+    unsigned long long *state;   // [B][nseg] look-back words
+    int *ticket;                 // [B]
+    int *err;                    // [1]
+    int nseg;
+};
+int launch_decode(const DecodeArgs &a, hipStream_t s);
+
+struct NmsArgs {
+    const float *boxes, *scores;
+    const int *counts, *src_idx;
+    int B, cap, C, per_class, total;
+    float iou_thr, score_thr;
+    float *out_boxes, *out_scores, *out_classes;
+    int *out_valid, *out_keep;
+    unsigned long long *kept_keys;   // [B][C][per_class]
+    int *kept_cnt;                   // [B][C]
+};
+int launch_nms(const NmsArgs &a, hipStream_t s);
+
+}  // namespace ymx

@@ -1,0 +1,248 @@
+// Combined (per-class, then per-image top-k) non-maximum suppression for gfx950.
+//
+// Kernel 1, one workgroup per (class, image): streams the class's score row (the
+// score matrix is class-major, so the row is contiguous: coalesced 16-byte loads,
+// every score byte read once) and selects candidates in exact (score desc, index
+// asc) order without sorting the row:
+//   - every candidate is a 64-bit key  ord(score) << 32 | ~index,  so one unsigned
+//     compare gives the visiting order;
+//   - keys above the score threshold and above a rising floor are appended to an
+//     LDS buffer (wavefront ballot + one LDS atomic per wave);  when the buffer
+//     cannot take another chunk it is bitonic-sorted, cut to its best 512 keys, and
+//     the 512th key becomes the new floor.  At the end the buffer holds exactly the
+//     keys >= floor, sorted;
+//   - wave 0 then runs the greedy suppression over that list in batches of 64: a
+//     lane tests its candidate against every box kept so far (the kept boxes live
+//     one per lane in registers and are broadcast with readlane), a ballot gives
+//     the bit mask of still-alive lanes, and the mask is resolved leader by leader;
+//   - if the list runs out before per_class boxes are kept and keys were cut, the
+//     scan repeats below the last visited key (a further tier).  The result is the
+//     exact greedy NMS for any input; the tiers only matter for speed.
+// Kernel 2, one workgroup per image: bitonic-sorts the kept entries of all classes
+// by (score desc, class asc, index asc) in LDS and writes the first `total`.
+//
+// IoU arithmetic is fp32, in a fixed order, compiled without contraction, with a
+// correctly rounded division, so keep decisions are reproducible bit for bit.
+#include "common.h"
+
+namespace ymx {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int NMS_KEEP = 512;     // keys that survive a cut
+constexpr int NMS_BUF = 2048;     // LDS key buffer
+constexpr int NMS_CHUNK = 1024;   // candidates scanned between capacity checks
+
+__device__ __forceinline__ u32 ord_bits(float s) {
+    const u32 u = __float_as_uint(s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unord_bits(u32 u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// Descending bitonic sort of n (a power of two) keys in LDS by 256 threads.
+__device__ __forceinline__ void bitonic_desc(u64 *buf, int n, int t) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < (n >> 1); i += 256) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int hi = lo | j;
+                const bool desc = (lo & k) == 0;
+                const u64 x = buf[lo], y = buf[hi];
+                if (desc ? (x < y) : (x > y)) { buf[lo] = y; buf[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// true iff IoU(a, b) > thr.  Boxes are normalised (min corner first); areas given.
+__device__ __forceinline__ bool iou_gt(float ay1, float ax1, float ay2, float ax2, float aar,
+                                       float by1, float bx1, float by2, float bx2, float bar, float thr) {
+    if (!(aar > 0.0f) || !(bar > 0.0f)) return false;
+    const float iy1 = fmaxf(ay1, by1), ix1 = fmaxf(ax1, bx1);
+    const float iy2 = fminf(ay2, by2), ix2 = fminf(ax2, bx2);
+    const float inter = fmaxf(iy2 - iy1, 0.0f) * fmaxf(ix2 - ix1, 0.0f);
+    const float uni = (aar + bar) - inter;
+    return (inter / uni) > thr;
+}
+
+__global__ void __launch_bounds__(256)
+nms_class_kernel(const NmsArgs a) {
+    __shared__ u64 buf[NMS_BUF];
+    __shared__ u64 s_last;
+    __shared__ int s_cnt, s_nkept;
+
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63;
+    int M = a.counts ? a.counts[b] : a.cap;
+    M = M > a.cap ? a.cap : (M < 0 ? 0 : M);
+    const float *__restrict__ col = a.scores + ((size_t)b * a.C + c) * a.cap;
+    const float4 *__restrict__ boxes4 = (const float4 *)a.boxes + (size_t)b * a.cap;
+    const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int PC = a.per_class;
+
+    // wave 0: kept box j lives in lane j
+    float ky1 = 0.f, kx1 = 0.f, ky2 = 0.f, kx2 = 0.f, kar = 0.f;
+    u64 kkey = 0;
+    int nkept = 0;
+    u64 ceil_key = ~0ull;           // keys must be < ceil_key
+
+    for (;;) {   // one pass per tier
+        if (t == 0) s_cnt = 0;
+        __syncthreads();
+        u64 floor_key = 0;          // keys must be > floor_key
+        bool cut = false;
+        for (int base = 0; base < M; base += NMS_CHUNK) {
+            const int i0 = base + t * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i0 < M) v = *(const float4 *)(col + i0);
+            const float sv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = i0 + e;
+                const float s = sv[e];
+                const u64 key = ((u64)ord_bits(s) << 32) | (u64)(0xffffffffu - (u32)idx);
+                const bool pred = idx < M && s > a.score_thr && key > floor_key && key < ceil_key;
+                const u64 bal = __ballot(pred);
+                if (bal) {
+                    const int leader = __ffsll((long long)bal) - 1;
+                    int pos = 0;
+                    if (lane == leader) pos = atomicAdd(&s_cnt, __popcll(bal));
+                    pos = __shfl(pos, leader);
+                    if (pred) buf[pos + __popcll(bal & below)] = key;
+                }
+            }
+            __syncthreads();
+            const int cnt = s_cnt;
+            if (cnt > NMS_BUF - NMS_CHUNK) {
+                for (int i = cnt + t; i < NMS_BUF; i += 256) buf[i] = 0;
+                __syncthreads();
+                bitonic_desc(buf, NMS_BUF, t);
+                floor_key = buf[NMS_KEEP - 1];
+                cut = true;
+                __syncthreads();
+                if (t == 0) s_cnt = NMS_KEEP;
+                __syncthreads();
+            }
+        }
+        const int n = s_cnt;
+        int nsort = 64;
+        while (nsort < n) nsort <<= 1;
+        for (int i = n + t; i < nsort; i += 256) buf[i] = 0;
+        __syncthreads();
+        bitonic_desc(buf, nsort, t);
+
+        if (t < 64) {
+            for (int base = 0; base < n && nkept < PC; base += 64) {
+                const int e = base + lane;
+                const bool valid = e < n;
+                const u64 key = valid ? buf[e] : 0ull;
+                const u32 idx = 0xffffffffu - (u32)key;
+                float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid) bx = boxes4[idx];
+                const float y1 = fminf(bx.x, bx.z), x1 = fminf(bx.y, bx.w);
+                const float y2 = fmaxf(bx.x, bx.z), x2 = fmaxf(bx.y, bx.w);
+                const float ar = (y2 - y1) * (x2 - x1);
+                bool alive = valid;
+                for (int j = 0; j < nkept; ++j) {
+                    const float by1 = __shfl(ky1, j), bx1 = __shfl(kx1, j);
+                    const float by2 = __shfl(ky2, j), bx2 = __shfl(kx2, j);
+                    const float bar = __shfl(kar, j);
+                    if (iou_gt(y1, x1, y2, x2, ar, by1, bx1, by2, bx2, bar, a.iou_thr)) alive = false;
+                }
+                u64 m = __ballot(alive);
+                while (m != 0 && nkept < PC) {
+                    const int l = __ffsll((long long)m) - 1;
+                    const float ly1 = __shfl(y1, l), lx1 = __shfl(x1, l);
+                    const float ly2 = __shfl(y2, l), lx2 = __shfl(x2, l);
+                    const float lar = __shfl(ar, l);
+                    const u32 klo = __shfl((u32)key, l), khi = __shfl((u32)(key >> 32), l);
+                    if (lane == nkept) {
+                        ky1 = ly1; kx1 = lx1; ky2 = ly2; kx2 = lx2; kar = lar;
+                        kkey = ((u64)khi << 32) | klo;
+                    }
+                    ++nkept;
+                    if (lane <= l || iou_gt(y1, x1, y2, x2, ar, ly1, lx1, ly2, lx2, lar, a.iou_thr)) alive = false;
+                    m = __ballot(alive);
+                }
+            }
+            if (t == 0) {
+                s_nkept = nkept;
+                s_last = n > 0 ? buf[n - 1] : 0ull;
+            }
+        }
+        __syncthreads();
+        const int nk = s_nkept;
+        if (nk >= PC || !cut || n == 0) break;
+        ceil_key = s_last;
+        __syncthreads();
+    }
+    if (t < 64) {
+        if (lane < nkept) a.kept_keys[((size_t)b * a.C + c) * PC + lane] = kkey;
+        if (lane == 0) a.kept_cnt[b * a.C + c] = nkept;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+nms_merge_kernel(const NmsArgs a, const int npow2) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    u64 *keys = (u64 *)smem_raw;
+    int &s_n = *(int *)(keys + npow2);      // all LDS in the one dynamic array
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int PC = a.per_class, nslots = a.C * PC;
+    if (t == 0) s_n = 0;
+    for (int i = t; i < npow2; i += 256) {
+        u64 key = 0;
+        if (i < nslots) {
+            const int c = i / PC, j = i - c * PC;
+            if (j < a.kept_cnt[b * a.C + c]) {
+                const u64 k1 = a.kept_keys[((size_t)b * a.C + c) * PC + j];
+                const u32 idx = 0xffffffffu - (u32)k1;
+                key = (k1 & 0xffffffff00000000ull) | ((u64)(0x7ffu - (u32)c) << 21) | (u64)(0x1fffffu - idx);
+            }
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    bitonic_desc(keys, npow2, t);
+    for (int i = t; i < npow2; i += 256)
+        if (keys[i] != 0 && (i + 1 == npow2 || keys[i + 1] == 0)) s_n = i + 1;
+    __syncthreads();
+    const int nvalid = s_n < a.total ? s_n : a.total;
+    if (t == 0) a.out_valid[b] = nvalid;
+    for (int j = t; j < a.total; j += 256) {
+        float4 ob = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sc = 0.f, cl = 0.f;
+        int kidx = -1;
+        if (j < nvalid) {
+            const u64 key = keys[j];
+            const u32 c = 0x7ffu - (u32)((key >> 21) & 0x7ffu);
+            const u32 idx = 0x1fffffu - (u32)(key & 0x1fffffu);
+            const float4 bx = ((const float4 *)a.boxes)[(size_t)b * a.cap + idx];
+            ob = make_float4(fminf(fmaxf(bx.x, 0.f), 1.f), fminf(fmaxf(bx.y, 0.f), 1.f),
+                             fminf(fmaxf(bx.z, 0.f), 1.f), fminf(fmaxf(bx.w, 0.f), 1.f));
+            sc = unord_bits((u32)(key >> 32));
+            cl = (float)c;
+            kidx = a.src_idx ? a.src_idx[(size_t)b * a.cap + idx] : (int)idx;
+        }
+        ((float4 *)a.out_boxes)[(size_t)b * a.total + j] = ob;
+        a.out_scores[(size_t)b * a.total + j] = sc;
+        a.out_classes[(size_t)b * a.total + j] = cl;
+        a.out_keep[(size_t)b * a.total + j] = kidx;
+    }
+}
+
+int launch_nms(const NmsArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(nms_class_kernel, dim3(a.C, a.B), dim3(256), 0, s, a);
+    int rc = check_launch("nms_class");
+    if (rc) return rc;
+    int npow2 = 256;
+    while (npow2 < a.C * a.per_class) npow2 <<= 1;
+    hipLaunchKernelGGL(nms_merge_kernel, dim3(a.B), dim3(256), (size_t)npow2 * 8 + 16, s, a, npow2);
+    return check_launch("nms_merge");
+}
+
+}  // namespace ymx

@@ -1,0 +1,289 @@
+"""Conv blocks of the detector, same names and signatures as the reference's layers.py.
+
+Every class mirrors /root/reference/layers.py (line numbers in each docstring).
+Tensors are NHWC on a GPU; kernels are stored HWIO in fp32 like Keras stores them and
+packed for the MFMA kernels on first use.  All device work goes through libymx.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+
+BN_EPSILON = 1e-3      # Keras BatchNormalization default, used unchanged at layers.py:4
+
+
+def _empty_like_nhwc(x, channels, h=None, w=None, dtype=None):
+    return torch.empty((x.shape[0], h if h is not None else x.shape[1],
+                        w if w is not None else x.shape[2], channels),
+                       device=x.device, dtype=dtype if dtype is not None else x.dtype)
+
+
+def _as_nhwc(x):
+    if x.dim() != 4:
+        raise ValueError("expected an NHWC tensor [B,H,W,C], got shape %s" % (tuple(x.shape),))
+    _lib.require_gpu(x)
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def affine_act(x, scale, shift, act):
+    """y = act(x*scale[c] + shift[c]) over the last axis (ymx_affine_act)."""
+    _lib.require_gpu(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    c = x.shape[-1]
+    _lib.check(_lib.lib().ymx_affine_act(_lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y),
+                                         x.numel() // c, c, act, _lib.dtype_code(x.dtype), _lib.stream()))
+    return y
+
+
+class BatchNormalization(nn.Module):
+    """Inference-statistics batch norm over the last axis (layers.py:4-15).
+
+    The reference forces ``training = training and trainable`` and then defers to
+    Keras; this package covers the inference form only, so a call that would use
+    batch statistics raises instead of silently normalising differently.
+    """
+
+    def __init__(self, num_features=None, epsilon=BN_EPSILON):
+        super().__init__()
+        self.epsilon = epsilon
+        self.trainable = True
+        self.num_features = None
+        if num_features is not None:
+            self.build(num_features)
+
+    def build(self, num_features):
+        self.num_features = num_features
+        self.gamma = nn.Parameter(torch.ones(num_features))
+        self.beta = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("moving_mean", torch.zeros(num_features))
+        self.register_buffer("moving_variance", torch.ones(num_features))
+
+    def folded(self):
+        """(scale, shift) with y = x*scale + shift, fp32 on the parameters' device."""
+        with torch.no_grad():
+            scale = self.gamma.float() / torch.sqrt(self.moving_variance.float() + self.epsilon)
+            shift = self.beta.float() - self.moving_mean.float() * scale
+        return scale.contiguous(), shift.contiguous()
+
+    def forward(self, x, training=False):
+        if training and self.trainable:
+            raise NotImplementedError("BatchNormalization: batch-statistics (training) mode is not part "
+                                      "of the inference hot path")
+        if self.num_features is None:
+            self.build(x.shape[-1])
+            self.to(x.device)
+        scale, shift = self.folded()
+        return affine_act(x, scale, shift, _lib.ACT_NONE)
+
+
+class Mish(nn.Module):
+    """x * tanh(softplus(x)) (layers.py:17-22)."""
+
+    def forward(self, x):
+        return affine_act(x, None, None, _lib.ACT_MISH)
+
+
+class RouteGroup(nn.Module):
+    """tf.split(x, groups, axis=-1)[group_id] as a zero-copy view (layers.py:24-31)."""
+
+    def __init__(self, groups, group_id):
+        super().__init__()
+        self.groups = groups
+        self.group_id = group_id
+
+    def forward(self, x):
+        c = x.shape[-1]
+        if c % self.groups:
+            raise ValueError("RouteGroup: %d channels do not split into %d groups" % (c, self.groups))
+        return torch.split(x, c // self.groups, dim=-1)[self.group_id]
+
+
+def upsample2x_concat(skip, x):
+    """[skip, bilinear_x2(x)] along channels in one kernel (ymx_upsample2x_concat)."""
+    x = _as_nhwc(x)
+    b, h, w, c2 = x.shape
+    c1 = 0
+    if skip is not None:
+        skip = _as_nhwc(skip)
+        if skip.shape[:3] != (b, 2 * h, 2 * w) or skip.dtype != x.dtype:
+            raise ValueError("upsample2x_concat: skip %s does not match 2x of %s" % (tuple(skip.shape), tuple(x.shape)))
+        c1 = skip.shape[3]
+    y = _empty_like_nhwc(x, c1 + c2, 2 * h, 2 * w)
+    _lib.check(_lib.lib().ymx_upsample2x_concat(_lib.ptr(skip), _lib.ptr(x), _lib.ptr(y), b, h, w, c1, c2,
+                                                _lib.dtype_code(x.dtype), _lib.stream()))
+    return y
+
+
+class Upsample(nn.Module):
+    """Bilinear x2, half-pixel centres, edge clamp (layers.py:33-39)."""
+
+    def forward(self, x):
+        return upsample2x_concat(None, x)
+
+
+class YOLOConv(nn.Module):
+    """[pad top/left] -> Conv2D -> [BatchNormalization] -> [activation] (layers.py:41-90).
+
+    filters_shape = (kh, kw, Cout).  downsample: stride 2 with one zero row/column on
+    the top/left only, VALID (layers.py:46-54); else stride 1 SAME (layers.py:55-57).
+    use_bias = not batchNormalization (layers.py:61).  activation: "mish" (default),
+    "leaky" (slope 0.1), a callable, or anything falsy for none; any other value
+    raises ValueError (layers.py:71-83).  Kernel init N(0, 0.01^2), bias 0
+    (layers.py:62-63).  Keras builds the kernel when it first sees an input; so does
+    this class (or pass in_channels= / call build()).
+
+    Extra keyword arguments: name (kept), dtype (torch.float32 or torch.bfloat16: the
+    compute type; default = the input's type), in_channels.
+    """
+
+    def __init__(self, filters_shape, downsample=False, batchNormalization=False, activation="mish", **kwargs):
+        super().__init__()
+        self.name = kwargs.pop("name", None)
+        self.compute_dtype = kwargs.pop("dtype", None)
+        in_channels = kwargs.pop("in_channels", None)
+        kwargs.pop("trainable", None)
+        if kwargs:
+            raise TypeError("YOLOConv: unexpected keyword arguments %s" % sorted(kwargs))
+        if len(filters_shape) != 3 or filters_shape[0] != filters_shape[1]:
+            raise ValueError("filters_shape must be (k, k, filters), got %s" % (tuple(filters_shape),))
+        self.kernel_size = int(filters_shape[0])
+        self.filters = int(filters_shape[-1])
+        self.downsample = bool(downsample)
+        self.batch_normalization = bool(batchNormalization)
+        self.act_fn = None
+        if activation:
+            if callable(activation):
+                self.act_code = _lib.ACT_NONE
+                self.act_fn = activation
+            elif activation == "leaky":
+                self.act_code = _lib.ACT_LEAKY
+            elif activation == "mish":
+                self.act_code = _lib.ACT_MISH
+            else:
+                raise ValueError("Activation should either be a function or one of \"leaky\" or \"mish\".")
+        else:
+            self.act_code = _lib.ACT_NONE
+        self.bn = BatchNormalization(self.filters) if self.batch_normalization else None
+        self.in_channels = None
+        self._packed = {}
+        if in_channels is not None:
+            self.build(in_channels)
+
+    # -- parameters -------------------------------------------------------------
+    def build(self, in_channels, generator=None):
+        k = self.kernel_size
+        self.in_channels = int(in_channels)
+        self.kernel = nn.Parameter(torch.randn(k, k, self.in_channels, self.filters, generator=generator) * 0.01)
+        if not self.batch_normalization:
+            self.bias = nn.Parameter(torch.zeros(self.filters))
+        self._packed = {}
+        return self
+
+    def load_reference_params(self, p):
+        """Copy a parameter dict {'kernel', 'bias' | 'gamma','beta','mean','var'}."""
+        if self.in_channels is None:
+            self.build(p["kernel"].shape[2])
+        with torch.no_grad():
+            self.kernel.copy_(p["kernel"])
+            if self.batch_normalization:
+                self.bn.gamma.copy_(p["gamma"]); self.bn.beta.copy_(p["beta"])
+                self.bn.moving_mean.copy_(p["mean"]); self.bn.moving_variance.copy_(p["var"])
+            else:
+                self.bias.copy_(p["bias"])
+        self._packed = {}
+
+    def packed(self, dtype):
+        """(weights packed for libymx, scale or None, shift) for a compute dtype."""
+        dev = self.kernel.device
+        key = (dtype, dev, self.kernel._version,
+               self.bias._version if not self.batch_normalization else
+               (self.bn.gamma._version, self.bn.beta._version, self.bn.moving_mean._version,
+                self.bn.moving_variance._version))
+        hit = self._packed.get("entry")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        _lib.require_gpu(self.kernel)
+        code = _lib.dtype_code(dtype)
+        k, cin, cout = self.kernel_size, self.in_channels, self.filters
+        nbytes = _lib.lib().ymx_packed_weight_bytes(k, cin, cout, code)
+        wp = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        src = self.kernel.detach().float().contiguous()
+        _lib.check(_lib.lib().ymx_pack_weights(_lib.ptr(src), _lib.ptr(wp), k, cin, cout, code, _lib.stream()))
+        if self.batch_normalization:
+            scale, shift = self.bn.folded()
+        else:
+            scale, shift = None, self.bias.detach().float().contiguous()
+        entry = (wp, scale, shift, src)      # src kept alive until the pack kernel has run
+        self._packed["entry"] = (key, entry)
+        return entry
+
+    # -- geometry ---------------------------------------------------------------
+    def output_hw(self, h, w):
+        if not self.downsample:
+            return h, w
+        k = self.kernel_size
+        return (h + 1 - k) // 2 + 1, (w + 1 - k) // 2 + 1
+
+    # -- forward ----------------------------------------------------------------
+    def forward(self, x, residual=None, out_dtype=None):
+        """x NHWC -> NHWC.  residual (same shape as the output) is added after the
+        activation inside the kernel; out_dtype overrides the output element type."""
+        x = _as_nhwc(x)
+        if self.in_channels is None:
+            self.build(x.shape[-1])
+            self.to(x.device)
+        if x.shape[-1] != self.in_channels:
+            raise ValueError("YOLOConv %s: expected %d input channels, got %d" % (self.name or "", self.in_channels, x.shape[-1]))
+        cdt = self.compute_dtype or x.dtype
+        code = _lib.dtype_code(cdt)
+        k, cin, cout = self.kernel_size, self.in_channels, self.filters
+        mfma = (cin % 8 == 0) if code == _lib.BF16 else (cin % 4 == 0)
+        if mfma and x.dtype != cdt:
+            x = x.to(cdt)
+        odt = out_dtype or cdt
+        wp, scale, shift, _ = self.packed(cdt)
+        b, h, w, _c = x.shape
+        oh, ow = self.output_hw(h, w)
+        y = _empty_like_nhwc(x, cout, oh, ow, dtype=odt)
+        fuse_res = residual is not None and self.act_fn is None
+        if fuse_res:
+            residual = _as_nhwc(residual)
+            want = cdt if mfma else odt
+            if residual.shape != y.shape:
+                raise ValueError("YOLOConv: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+            if residual.dtype != want:
+                residual = residual.to(want)
+        _lib.check(_lib.lib().ymx_conv2d_fused_ex(
+            _lib.ptr(x), _lib.ptr(wp), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual) if fuse_res else None,
+            _lib.ptr(y), b, h, w, cin, cout, k, 2 if self.downsample else 1, self.act_code, code,
+            _lib.dtype_code(x.dtype), _lib.dtype_code(odt), 0, 0, 0, _lib.stream()))
+        if self.act_fn is not None:
+            y = self.act_fn(y)
+            if residual is not None:
+                y = residual + y
+        return y
+
+
+class ResidialBlock(nn.Module):
+    """x + conv3x3(conv1x1(x)); the add follows the second activation (layers.py:92-106).
+
+    The spelling is the reference's.  The add is fused into the 3x3 conv's epilogue.
+    """
+
+    def __init__(self, filter_num1, filter_num2, activation="mish", **kwargs):
+        super().__init__()
+        dtype = kwargs.pop("dtype", None)
+        if kwargs:
+            raise TypeError("ResidialBlock: unexpected keyword arguments %s" % sorted(kwargs))
+        self.layer_stack = nn.ModuleList([
+            YOLOConv(filters_shape=(1, 1, filter_num1), activation=activation, dtype=dtype),
+            YOLOConv(filters_shape=(3, 3, filter_num2), activation=activation, dtype=dtype),
+        ])
+
+    def forward(self, x):
+        short_cut = x
+        x = self.layer_stack[0](x)
+        return self.layer_stack[1](x, residual=short_cut)
