@@ -159,7 +159,7 @@ def init_params(specs, seed=0, init="reference", batch_norm=False, bn_random=Fal
     return params
 
 
-def darknet53_forward(params, x, act="mish", round_fn=None):
+def darknet53_forward(params, x, act="mish", round_fn=None, hook=None):
     """x [B,S,S,3] -> (scale_1 [B,S/8,S/8,256], scale_2 [..,512], scale_3 [..,1024]).
 
     backbones.py:44-60.  ResidialBlock adds the shortcut after the second
@@ -170,13 +170,15 @@ def darknet53_forward(params, x, act="mish", round_fn=None):
     rf = round_fn if round_fn is not None else (lambda t: t)
     it = iter(zip(specs, params))
 
-    def conv(x):
+    def conv(x, kind="main"):
         (k, cin, cout, down, a), p = next(it)
+        if hook is not None:
+            hook(p, x, down, kind)
         return yolo_conv(x, p, down, act if a is not None else None)
 
     def res(x):
         y = rf(conv(x))
-        y = conv(y)
+        y = conv(y, "res2")
         return rf(x + y)
 
     x = rf(conv(x)); x = rf(conv(x))
@@ -195,7 +197,7 @@ def darknet53_forward(params, x, act="mish", round_fn=None):
     return s1, s2, s3
 
 
-def yolov3_forward(params, s1, s2, s3, num_classes, act="mish", round_fn=None):
+def yolov3_forward(params, s1, s2, s3, num_classes, act="mish", round_fn=None, hook=None):
     """(scale_1, scale_2, scale_3) -> (sbbox, mbbox, lbbox) raw conv maps.
 
     detectors.py:46-77: five convs at /32, lbbox branch, upsample + concat
@@ -208,6 +210,8 @@ def yolov3_forward(params, s1, s2, s3, num_classes, act="mish", round_fn=None):
 
     def conv(x, final=False):
         (k, cin, cout, down, a), p = next(it)
+        if hook is not None:
+            hook(p, x, down, "out" if final else "main")
         y = yolo_conv(x, p, down, act if a is not None else None)
         return y if final else rf(y)
 
@@ -225,9 +229,48 @@ def yolov3_forward(params, s1, s2, s3, num_classes, act="mish", round_fn=None):
     return s, m, l
 
 
-def detector_forward(bparams, hparams, x, num_classes, act="mish", round_fn=None):
-    s1, s2, s3 = darknet53_forward(bparams, x, act, round_fn)
-    return yolov3_forward(hparams, s1, s2, s3, num_classes, act, round_fn)
+def detector_forward(bparams, hparams, x, num_classes, act="mish", round_fn=None, hook=None):
+    s1, s2, s3 = darknet53_forward(bparams, x, act, round_fn, hook)
+    return yolov3_forward(hparams, s1, s2, s3, num_classes, act, round_fn, hook)
+
+
+def calibrated_params(num_classes, seed=0, side=64, out_std=2.0, conf_bias=0.0):
+    """Random parameters whose activations stay O(1) through all 73 layers.
+
+    The reference's own init (N(0, 0.01^2), layers.py:62) collapses every activation
+    towards 0, and a fan-in init explodes through the 23 shortcut adds, so neither
+    exercises the kernels.  Here every kernel is drawn N(0, 1) and then rescaled, layer by
+    layer in execution order on a seeded calibration image, so that its pre-activation has
+    unit standard deviation (0.5 on the second conv of a residual block, out_std on the
+    three linear output convs).  Deterministic for a given (num_classes, seed, side).
+    Returns (backbone_params, head_params).
+    """
+    g = torch.Generator().manual_seed(seed)
+    bspecs, hspecs = darknet53_specs(), yolov3_specs(num_classes)
+
+    def draw(specs):
+        out = []
+        for (k, cin, cout, _d, _a) in specs:
+            out.append({"kernel": torch.randn(k, k, cin, cout, generator=g) / math.sqrt(k * k * cin),
+                        "bias": torch.zeros(cout)})
+        return out
+
+    bp, hp = draw(bspecs), draw(hspecs)
+    x = torch.rand(2, side, side, 3, generator=g)
+
+    def hook(p, xin, down, kind):
+        target = {"main": 1.0, "res2": 0.5, "out": out_std}[kind]
+        z = yolo_conv(xin, {"kernel": p["kernel"], "bias": None}, down, None)
+        p["kernel"] = p["kernel"] * (target / float(z.std()))
+        if kind == "out":
+            b = torch.zeros(p["kernel"].shape[3])
+            b.view(3, -1)[:, 4] = conf_bias
+            p["bias"] = b
+        else:
+            p["bias"] = 0.05 * torch.randn(p["kernel"].shape[3], generator=g)
+
+    detector_forward(bp, hp, x, num_classes, hook=hook)
+    return bp, hp
 
 
 def bf16_round(t):

@@ -1,0 +1,405 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI (via the Python
+modules), against the CPU oracle on identical inputs.
+
+Tolerances (the ones the task states): fp32 results within 1e-3 relative, bf16 within
+1e-2 relative; NMS outputs and compaction indices bit-exact on identical decoded
+inputs.  "Relative" for conv outputs is against the tensor's scale (max |reference|),
+since individual outputs of a convolution can cancel to ~0.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+from oracle import net_torch as N
+from oracle import postproc_np as P
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+F = np.float32
+
+
+def rel_err(got, want):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+def tol_for(dtype):
+    return 1e-3 if dtype == torch.float32 else 1e-2
+
+
+def make_conv(p, k, down, act, bn, dtype, out_dtype=None):
+    from yolo_amd.layers import YOLOConv
+    cin, cout = p["kernel"].shape[2], p["kernel"].shape[3]
+    layer = YOLOConv((k, k, cout), downsample=down, batchNormalization=bn, activation=act, dtype=dtype)
+    layer.load_reference_params(p)
+    return layer.to(DEV)
+
+
+# ----------------------------------------------------------------------------- conv
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_goldens(golden_dir, dtype):
+    files = sorted(glob.glob(os.path.join(golden_dir, "conv_*.npz")))
+    assert len(files) == 5
+    for f in files:
+        g = np.load(f)
+        p = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("p_")}
+        act = str(g["act"])
+        layer = make_conv(p, int(g["k"]), bool(g["down"]), None if act == "none" else act, "gamma" in p, dtype)
+        x = torch.from_numpy(g["x"]).to(DEV)
+        first = x.shape[-1] == 3
+        xin = x if first else x.to(dtype)            # the first layer takes the fp32 image as is
+        res = torch.from_numpy(g["residual"]).to(DEV).to(dtype) if "residual" in g.files else None
+        y = layer(xin, residual=res)
+        assert y.dtype == dtype and tuple(y.shape) == g["y"].shape
+        e = rel_err(y.float().cpu().numpy(), g["y"])
+        assert e < tol_for(dtype), (os.path.basename(f), e)
+
+
+CONV_SHAPES = [
+    # B, H, W, Cin, Cout, k, down, act, residual, bn
+    (2, 13, 13, 64, 255, 1, False, None, False, False),      # head output conv, Cout % 4 != 0
+    (1, 26, 26, 32, 64, 3, False, "mish", True, False),      # Cin 32: a K step spans two taps
+    (2, 8, 8, 768, 512, 1, False, "mish", False, False),     # concat width, not a power of two
+    (1, 16, 16, 64, 32, 1, False, "leaky", False, True),     # narrow output tile
+    (1, 20, 20, 128, 256, 3, True, "mish", False, False),    # downsample, even size
+    (1, 13, 13, 512, 1024, 3, False, "mish", True, False),   # K = 4608, the heavy shape
+    (3, 7, 9, 8, 24, 3, False, "mish", False, False),        # smallest MFMA-eligible channels (bf16)
+    (1, 11, 11, 16, 48, 5, False, None, False, False),       # 5x5
+    (1, 9, 9, 3, 20, 3, True, "mish", False, False),         # direct path, odd sizes, downsample
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", range(len(CONV_SHAPES)))
+def test_conv_random_shapes(case, dtype):
+    B, H, W, cin, cout, k, down, act, use_res, bn = CONV_SHAPES[case]
+    g = torch.Generator().manual_seed(100 + case)
+    x = N.bf16_round(torch.randn(B, H, W, cin, generator=g))
+    p = {"kernel": N.bf16_round(torch.randn(k, k, cin, cout, generator=g) * (2.0 / (k * k * cin)) ** 0.5)}
+    if bn:
+        p.update(gamma=1 + 0.2 * torch.randn(cout, generator=g), beta=0.1 * torch.randn(cout, generator=g),
+                 mean=0.1 * torch.randn(cout, generator=g), var=0.5 + torch.rand(cout, generator=g))
+    else:
+        p["bias"] = 0.1 * torch.randn(cout, generator=g)
+    want = N.yolo_conv(x, p, down, act)
+    res = None
+    if use_res:
+        res = N.bf16_round(torch.randn(*want.shape, generator=g))
+        want = want + res
+    layer = make_conv(p, k, down, act, bn, dtype)
+    xin = x.to(DEV) if cin == 3 else x.to(DEV).to(dtype)
+    y = layer(xin, residual=None if res is None else res.to(DEV).to(dtype))
+    e = rel_err(y.float().cpu().numpy(), want.numpy())
+    assert e < tol_for(dtype), e
+    if dtype == torch.bfloat16 and cin != 3:
+        # fp32 output from bf16 operands (what the head's output convs use)
+        y32 = layer(xin, residual=None if res is None else res.to(DEV).to(dtype), out_dtype=torch.float32)
+        assert y32.dtype == torch.float32 and rel_err(y32.cpu().numpy(), want.numpy()) < 1e-3
+
+
+def test_conv_plain_entry_point_and_strides():
+    """ymx_conv2d_fused (dense) and ymx_conv2d_fused_ex with pixel strides on both sides."""
+    from yolo_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    B, H, W, cin, cout = 2, 6, 5, 16, 32
+    x = N.bf16_round(torch.randn(B, H, W, cin, generator=g))
+    p = {"kernel": N.bf16_round(torch.randn(3, 3, cin, cout, generator=g) * 0.1), "bias": torch.randn(cout, generator=g)}
+    want = N.yolo_conv(x, p, False, "mish").numpy()
+    layer = make_conv(p, 3, False, "mish", False, torch.bfloat16)
+    wp, scale, shift, _ = layer.packed(torch.bfloat16)
+    L = _lib.lib()
+    xd = x.to(DEV).bfloat16()
+    y = torch.empty((B, H, W, cout), device=DEV, dtype=torch.bfloat16)
+    _lib.check(L.ymx_conv2d_fused(_lib.ptr(xd), _lib.ptr(wp), None, _lib.ptr(shift), None, _lib.ptr(y), B, H, W, cin,
+                                  cout, 3, 1, _lib.ACT_MISH, _lib.BF16, _lib.stream()))
+    assert rel_err(y.float().cpu().numpy(), want) < 1e-2
+    # input embedded in a wider buffer (x_ld = 24), output into channels 8.. of a 48-wide buffer
+    xw = torch.zeros((B, H, W, 24), device=DEV, dtype=torch.bfloat16)
+    xw[..., :cin] = xd
+    yw = torch.full((B, H, W, 48), 7.0, device=DEV, dtype=torch.bfloat16)
+    yv = yw[..., 8:]
+    _lib.check(L.ymx_conv2d_fused_ex(_lib.ptr(xw), _lib.ptr(wp), None, _lib.ptr(shift), None,
+                                     yv.data_ptr(), B, H, W, cin, cout, 3, 1, _lib.ACT_MISH, _lib.BF16, _lib.BF16,
+                                     _lib.BF16, 24, 0, 48, _lib.stream()))
+    assert torch.equal(yw[..., 8:40], y) and bool((yw[..., :8] == 7).all()) and bool((yw[..., 40:] == 7).all())
+
+
+def test_layers_standalone():
+    from yolo_amd import layers
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 5, 7, 16, generator=g) * 4
+    got = layers.Mish()(x.to(DEV)).cpu()
+    assert rel_err(got.numpy(), N.mish(x).numpy()) < 1e-5
+    got = layers.Mish()(x.to(DEV).bfloat16()).float().cpu()
+    assert rel_err(got.numpy(), N.mish(N.bf16_round(x)).numpy()) < 1e-2
+    bn = layers.BatchNormalization(16)
+    with torch.no_grad():
+        bn.gamma.copy_(torch.rand(16, generator=g) + 0.5); bn.beta.copy_(torch.randn(16, generator=g))
+        bn.moving_mean.copy_(torch.randn(16, generator=g)); bn.moving_variance.copy_(torch.rand(16, generator=g) + 0.5)
+    want = (x - bn.moving_mean) / torch.sqrt(bn.moving_variance + 1e-3) * bn.gamma.detach() + bn.beta.detach()
+    got = bn.to(DEV)(x.to(DEV)).cpu()
+    assert rel_err(got.numpy(), want.numpy()) < 1e-5
+    with pytest.raises(NotImplementedError):
+        bn(x.to(DEV), training=True)
+    r = layers.RouteGroup(2, 1)(x.to(DEV))
+    assert r.shape == (2, 5, 7, 8) and torch.equal(r.cpu(), x[..., 8:])
+    # callable activation runs after the kernel
+    p = {"kernel": torch.randn(1, 1, 16, 8, generator=g), "bias": torch.zeros(8)}
+    layer = layers.YOLOConv((1, 1, 8), activation=torch.relu)
+    layer.load_reference_params(p)
+    got = layer.to(DEV)(x.to(DEV)).cpu()
+    assert rel_err(got.numpy(), torch.relu(N.yolo_conv(x, p, False, None)).numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upsample_concat(golden_dir, dtype):
+    from yolo_amd import layers
+    g = np.load(os.path.join(golden_dir, "upsample.npz"))
+    x = torch.from_numpy(g["x"]).to(DEV).to(dtype)
+    y = layers.Upsample()(x)
+    assert rel_err(y.float().cpu().numpy(), g["y"]) < tol_for(dtype)
+    gen = torch.Generator().manual_seed(3)
+    a = N.bf16_round(torch.randn(2, 7, 4, 24, generator=gen))
+    skip = N.bf16_round(torch.randn(2, 14, 8, 8, generator=gen))
+    want = torch.cat([skip, N.upsample2x(a)], -1)
+    got = layers.upsample2x_concat(skip.to(DEV).to(dtype), a.to(DEV).to(dtype))
+    assert got.shape == want.shape
+    assert torch.equal(got[..., :8].float().cpu(), skip)
+    assert rel_err(got.float().cpu().numpy(), want.numpy()) < tol_for(dtype)
+
+
+# ----------------------------------------------------------------------------- decode / filter
+def _golden_heads(g):
+    return [g["head%d" % i] for i in range(3)]
+
+
+@pytest.mark.parametrize("name", ["postproc_c3", "postproc_c80", "postproc_c1"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decode_goldens(golden_dir, name, dtype):
+    import yolo_amd as Y
+    from yolo_amd import utils as U
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    C = int(g["C"])
+    heads_np = _golden_heads(g)
+    heads = [torch.from_numpy(h).to(DEV).to(dtype) for h in heads_np]
+    if dtype == torch.bfloat16:
+        want_b, want_s = P.decode_all([h.float().cpu().numpy() for h in heads], C)
+    else:
+        want_b, want_s = g["xywh"], g["scores"]
+    cfg = Y.config
+    # one call for all scales
+    r = U.decode_heads(heads, C, cfg["strides"], cfg["xyscale"], U.default_anchors())
+    n = r["N"]
+    assert n == want_b.shape[1] and r["counts"].cpu().tolist() == [n] * heads[0].shape[0]
+    got_b = r["boxes"][:, :n].cpu().numpy()
+    got_s = r["scores_cm"][:, :, :n].transpose(1, 2).cpu().numpy()
+    np.testing.assert_allclose(got_b, want_b, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(got_s, want_s, rtol=1e-3, atol=1e-6)
+    # the per-scale API functions of the reference
+    off = 0
+    for i, h in enumerate(heads):
+        S = h.shape[1]
+        bx, sc = Y.decode_predict(h, i, S, C, cfg["strides"], cfg["xyscale"], U.default_anchors())
+        m = 3 * S * S
+        assert bx.shape == (h.shape[0], m, 4) and sc.shape == (h.shape[0], m, C)
+        np.testing.assert_allclose(bx.cpu().numpy(), want_b[:, off:off + m], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(sc.cpu().numpy(), want_s[:, off:off + m], rtol=1e-3, atol=1e-6)
+        xywh, conf, prob = Y.decode(h, i, S, C, cfg["strides"], cfg["xyscale"], U.default_anchors())
+        w_xywh, w_conf, w_prob = P.decode(h.float().cpu().numpy(), i, S, C)
+        np.testing.assert_allclose(xywh.cpu().numpy(), w_xywh, rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(conf.cpu().numpy(), w_conf, rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(prob.cpu().numpy(), w_prob, rtol=1e-3, atol=1e-6)
+        tr = Y.decode_train(h, i, S, C, cfg["strides"], cfg["xyscale"], U.default_anchors())
+        np.testing.assert_allclose(tr.cpu().numpy(), P.decode_train(h.float().cpu().numpy(), i, S, C), rtol=1e-3, atol=1e-4)
+        off += m
+
+
+@pytest.mark.parametrize("name", ["postproc_c3", "postproc_c80", "postproc_c1"])
+def test_filter_goldens_exact(golden_dir, name):
+    """filter_bboxes on the golden decoded tensors: survivors, order and values exact."""
+    import yolo_amd as Y
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    xywh = torch.from_numpy(g["xywh"]).to(DEV)
+    scores = torch.from_numpy(g["scores"]).to(DEV)
+    for sc_in in (scores, scores.transpose(1, 2).contiguous().transpose(1, 2)):     # candidate- and class-major
+        out = Y.filter_bboxes(xywh, sc_in, float(g["thr"]), float(g["image_size"]))
+        boxes, sc = out
+        np.testing.assert_array_equal(out.counts.cpu().numpy(), g["f_counts"])
+        np.testing.assert_array_equal(out.src_idx.cpu().numpy(), g["f_src"])
+        np.testing.assert_array_equal(sc.cpu().numpy(), g["f_scores"])
+        np.testing.assert_allclose(boxes.cpu().numpy(), g["f_boxes"], rtol=1e-6, atol=1e-7)
+
+
+def _check_fused_filter(heads_t, C, thr, image_size):
+    """decode+filter in one launch vs the oracle applied to the GPU's own decode:
+    identical decoded inputs -> identical survivors, in order."""
+    import yolo_amd as Y
+    from yolo_amd import utils as U
+    cfg = Y.config
+    dec = U.decode_heads(heads_t, C, cfg["strides"], cfg["xyscale"], U.default_anchors())
+    n = dec["N"]
+    d_boxes = dec["boxes"][:, :n].cpu().numpy()
+    d_scores = dec["scores_cm"][:, :, :n].transpose(1, 2).cpu().numpy()
+    fb, fs, counts, src = cref.filter_bboxes(d_boxes, d_scores, thr, image_size)
+    r = U.decode_heads(heads_t, C, cfg["strides"], cfg["xyscale"], U.default_anchors(), filter=True,
+                       score_threshold=thr, image_size=image_size)
+    got_counts = r["counts"].cpu().numpy()
+    np.testing.assert_array_equal(got_counts, counts)
+    ws = r["workspace"].cpu().numpy().view(np.int32)
+    assert ws[0] == 0, "look-back spin limit hit"
+    for b in range(len(counts)):
+        m = int(counts[b])
+        np.testing.assert_array_equal(r["src_idx"][b, :m].cpu().numpy(), src[b, :m])
+        np.testing.assert_array_equal(r["scores_cm"][b, :, :m].cpu().numpy().T, fs[b, :m])
+        np.testing.assert_allclose(r["boxes"][b, :m].cpu().numpy(), fb[b, :m], rtol=1e-6, atol=1e-7)
+    return r, (fb, fs, counts, src)
+
+
+@pytest.mark.parametrize("name", ["postproc_c3", "postproc_c80", "postproc_c1"])
+def test_fused_decode_filter(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    heads = [torch.from_numpy(h).to(DEV) for h in _golden_heads(g)]
+    _check_fused_filter(heads, int(g["C"]), float(g["thr"]), float(g["image_size"]))
+
+
+def test_fused_decode_filter_416_edges():
+    """Real 416^2 geometry (52/26/13: ragged last segments), all-pass, none-pass, sparse."""
+    gen = torch.Generator().manual_seed(9)
+    C, B = 80, 3
+    heads = [torch.randn(B, S, S, 3, 5 + C, generator=gen) * 2 for S in (52, 26, 13)]
+    heads_t = [h.to(DEV) for h in heads]
+    for thr in (0.25, -1.0, 2.0, 0.9):
+        r, (_, _, counts, _) = _check_fused_filter(heads_t, C, thr, 416.0)
+        if thr < 0:
+            assert counts.tolist() == [10647] * B
+        if thr > 1:
+            assert counts.tolist() == [0] * B
+
+
+# ----------------------------------------------------------------------------- NMS
+def _gpu_nms(boxes, scores, counts, per_class, total, iou, thr, src=None):
+    import yolo_amd as Y
+    out = Y.combined_non_max_suppression(
+        torch.from_numpy(np.ascontiguousarray(boxes)).to(DEV)[:, :, None, :], torch.from_numpy(np.ascontiguousarray(scores)).to(DEV),
+        per_class, total, iou, thr, counts=None if counts is None else torch.from_numpy(counts).to(DEV),
+        src_idx=None if src is None else torch.from_numpy(src).to(DEV))
+    return [t.cpu().numpy() for t in out] + [out.keep_idx.cpu().numpy()]
+
+
+def _assert_nms_equal(got, want):
+    for a, b, name in zip(got, want, ("boxes", "scores", "classes", "valid", "keep_idx")):
+        np.testing.assert_array_equal(a, b, err_msg=name)
+
+
+@pytest.mark.parametrize("name", ["nms_dense", "nms_ties"])
+def test_nms_goldens_bit_exact(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    got = _gpu_nms(g["boxes"], g["scores"], g["counts"], int(g["per_class"]), int(g["total"]), float(g["iou"]), float(g["thr"]))
+    _assert_nms_equal(got, [g[k] for k in ("n_boxes", "n_scores", "n_classes", "n_valid", "n_keep")])
+
+
+@pytest.mark.parametrize("name", ["postproc_c3", "postproc_c80", "postproc_c1"])
+def test_nms_on_golden_filtered_inputs(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    got = _gpu_nms(g["f_boxes"], g["f_scores"], g["f_counts"], int(g["per_class"]), int(g["total"]), float(g["iou"]),
+                   float(g["thr"]), src=g["f_src"])
+    _assert_nms_equal(got, [g[k] for k in ("n_boxes", "n_scores", "n_classes", "n_valid", "n_keep")])
+
+
+def test_nms_edge_cases():
+    cases = [
+        ([[0, 0, .5, .5]] * 3, [[.9], [.8], [.7]], {}),                                    # identical boxes
+        ([[0, 0, .5, 1.0], [0, 0, .5, .5]], [[.9], [.8]], dict(iou=0.5)),                  # IoU == threshold: kept
+        ([[0, 0, .5, 1.0], [0, 0, .5, .5]], [[.9], [.8]], dict(iou=0.49)),
+        ([[0, 0, .1, .1], [.5, .5, .6, .6]], [[.25], [.26]], {}),                          # strict score threshold
+        ([[0, 0, .1, .1], [.5, .5, .6, .6], [.8, .8, .9, .9]], [[.5, .5]] * 3, {}),        # ties: class, then index
+        ([[0, 0, .5, .5], [0, 0, .5, .45], [.6, .6, .9, .9]], [[.7]] * 3, {}),             # tie inside a class
+        ([[.2, .2, .2, .6], [.2, .2, .2, .6], [.5, .5, 0, 0], [0, 0, .5, .5]], [[.9], [.8], [.7], [.6]], {}),
+        ([[-.2, -.1, .3, 1.4]] + [[.1 * i, .1 * i, .1 * i + .05, .1 * i + .05] for i in range(1, 9)],
+         [[.95]] + [[.9 - .01 * i] for i in range(1, 9)], dict(per_class=5, total=3)),     # clip + caps
+        ([[0, 0, 1, 1]], [[0.1]], {}),                                                     # nothing passes
+    ]
+    for boxes, scores, kw in cases:
+        b = np.asarray(boxes, F)[None]
+        s = np.asarray(scores, F)[None]
+        args = (kw.get("per_class", 32), kw.get("total", 32), kw.get("iou", 0.45), kw.get("thr", 0.25))
+        want = P.combined_nms(b, s, None, *args)
+        _assert_nms_equal(_gpu_nms(b, s, None, *args), want)
+
+
+def _random_boxes(rng, B, M, sigma=0.5, mu=-3.0):
+    cy, cx = rng.random((B, M)), rng.random((B, M))
+    h, w = np.exp(rng.normal(mu, sigma, (B, M))), np.exp(rng.normal(mu, sigma, (B, M)))
+    return np.stack([cy - h / 2, cx - w / 2, cy + h / 2, cx + w / 2], -1).astype(F)
+
+
+def test_nms_large_random_vs_c_oracle():
+    """20k candidates x 80 classes, threshold 0.001: many buffer cuts per class."""
+    rng = np.random.default_rng(5)
+    B, M, C = 3, 20000, 80
+    boxes = _random_boxes(rng, B, M)
+    scores = (rng.random((B, M, C)) ** 4).astype(F)
+    counts = np.array([M, M - 1237, 17], np.int32)
+    want = cref.combined_nms(boxes, scores, counts, 32, 32, 0.45, 0.001)
+    _assert_nms_equal(_gpu_nms(boxes, scores, counts, 32, 32, 0.45, 0.001), want)
+    want = cref.combined_nms(boxes, scores, counts, 64, 100, 0.3, 0.5)
+    _assert_nms_equal(_gpu_nms(boxes, scores, counts, 64, 100, 0.3, 0.5), want)
+
+
+def test_nms_deep_suppression_needs_further_tiers():
+    """Thousands of near-identical high-score boxes ahead of the few distinct ones: the
+    greedy pass must walk far past the first 512 candidates (several tiers)."""
+    rng = np.random.default_rng(6)
+    M, C = 6000, 2
+    boxes = np.tile(np.array([[.2, .2, .6, .6]], F), (M, 1)) + rng.normal(0, 1e-3, (M, 4)).astype(F)
+    scores = np.zeros((M, C), F)
+    scores[:, 0] = np.linspace(0.99, 0.5, M, dtype=F)
+    scores[:, 1] = (rng.random(M) * 0.4 + 0.5).astype(F)
+    distinct = rng.choice(M, 40, replace=False)
+    boxes[distinct] = _random_boxes(rng, 1, 40, mu=-3.5)[0]
+    scores[distinct, 0] = np.linspace(0.3, 0.26, 40, dtype=F)          # visited last
+    scores[:, 1] = np.round(scores[:, 1] * 32) / 32                    # heavy ties in class 1
+    b, s = boxes[None], scores[None]
+    want = cref.combined_nms(b, s, None, 32, 64, 0.45, 0.25)
+    assert want[3][0] > 33                                             # the distinct boxes were reached
+    _assert_nms_equal(_gpu_nms(b, s, None, 32, 64, 0.45, 0.25), want)
+
+
+def test_bbox_nms_end_to_end(golden_dir):
+    """heads -> bbox_nms in one go.  Compared with the oracle run on the GPU's own decoded
+    values (NMS is exact only on identical decoded inputs)."""
+    import yolo_amd as Y
+    for name in ("postproc_c3", "postproc_c80", "postproc_c1"):
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        C, thr, size = int(g["C"]), float(g["thr"]), float(g["image_size"])
+        heads = [torch.from_numpy(h).to(DEV) for h in _golden_heads(g)]
+        _, (fb, fs, counts, src) = _check_fused_filter(heads, C, thr, size)
+        want = cref.combined_nms(fb, fs, counts, int(g["per_class"]), int(g["total"]), float(g["iou"]), thr, src_idx=src)
+        raw = [h.reshape(h.shape[0], h.shape[1], h.shape[2], -1) for h in heads]      # [B,S,S,3(5+C)] conv maps
+        out = Y.bbox_nms(raw, size, int(g["per_class"]), int(g["total"]), float(g["iou"]), thr)
+        got = [t.cpu().numpy() for t in out] + [out.keep_idx.cpu().numpy()]
+        np.testing.assert_allclose(got[0], want[0], rtol=1e-6, atol=1e-7)
+        for a, b in zip(got[1:], want[1:]):
+            np.testing.assert_array_equal(a, b)
+        # and against the committed golden result (decode differences are far below any score gap here)
+        np.testing.assert_array_equal(got[4], g["n_keep"])
+        np.testing.assert_array_equal(got[3], g["n_valid"])
+
+
+def test_bbox_iou_giou():
+    import yolo_amd as Y
+    rng = np.random.default_rng(8)
+    a = rng.random((5, 1, 4)).astype(F) * 10
+    b = rng.random((1, 7, 4)).astype(F) * 10
+    b[0, 0] = 0
+    a[0, 0] = 0
+    for fn, ref in ((Y.bbox_iou, P.bbox_iou), (Y.bbox_giou, P.bbox_giou)):
+        got = fn(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)).cpu().numpy()
+        assert got.shape == (5, 7)
+        np.testing.assert_allclose(got, ref(a, b), rtol=1e-5, atol=1e-6)

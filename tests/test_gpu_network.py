@@ -1,0 +1,179 @@
+"""GPU parity of the whole detector against the CPU oracle, plus size-independent
+properties at the benchmark's full sizes (determinism, batch invariance).
+
+The oracle's conv stack is torch-CPU fp32.  For bf16 the oracle is run with the same
+storage roundings the HIP path has (weights and every stored activation rounded to
+bf16, fp32 accumulation), so the comparison isolates kernel arithmetic; the distance to
+the un-rounded fp32 oracle is reported as well.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+from oracle import net_torch as N
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_err(got, want):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+def _params(C, init, seed=0, side=64):
+    """'reference' = the reference's own N(0, 0.01^2) init (degenerate: activations
+    collapse to 0); 'variance' = parameters calibrated on a seeded image of the given
+    side so that every layer's activations stay O(1)."""
+    if init == "variance":
+        return N.calibrated_params(C, seed=seed, side=side)
+    return (N.init_params(N.darknet53_specs(), seed=seed, init=init),
+            N.init_params(N.yolov3_specs(C), seed=seed + 1, init=init))
+
+
+def _image(B, S, seed=1):
+    return torch.rand(B, S, S, 3, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.mark.parametrize("init", ["variance", "reference"])
+def test_modules_fp32_vs_oracle(init):
+    """Darknet53 -> YoloV3 through the module API, fp32 MFMA path, 64x64 input."""
+    from yolo_amd.backbones import Darknet53
+    from yolo_amd.detectors import YoloV3
+    C = 3
+    bp, hp = _params(C, init)
+    x = _image(2, 64)
+    want_s = N.darknet53_forward(bp, x)
+    want_h = N.yolov3_forward(hp, *want_s, C)
+    bb, hd = Darknet53(), YoloV3(C)
+    bb.load_reference_params(bp)
+    hd.load_reference_params(hp)
+    bb.to(DEV); hd.to(DEV)
+    got_s = bb(x.to(DEV))
+    got_h = hd(*got_s, training=False)
+    for g, w in zip(got_s, want_s):
+        assert g.shape == w.shape and g.dtype == torch.float32
+        assert rel_err(g.cpu().numpy(), w.numpy()) < 1e-3
+    for g, w in zip(got_h, want_h):
+        assert g.shape == w.shape and g.dtype == torch.float32
+        assert rel_err(g.cpu().numpy(), w.numpy()) < 1e-3
+
+
+def test_detector_bf16_vs_rounding_oracle():
+    """bf16 network (planned program) vs the oracle with identical storage roundings."""
+    from yolo_amd import Detector
+    C = 80
+    bp, hp = _params(C, "variance", side=96)
+    x = _image(2, 96)
+    det = Detector(num_classes=C, dtype=torch.bfloat16)
+    det.load_reference_params(bp, hp)
+    det.to(DEV)
+    heads = [h.clone() for h in det.forward_heads(x.to(DEV))]
+    assert all(h.dtype == torch.float32 for h in heads)
+    # the image itself is consumed in fp32 by the first layer; everything stored is bf16
+    want = N.detector_forward(N.round_params_bf16(bp), N.round_params_bf16(hp), x, C, round_fn=N.bf16_round)
+    pure = N.detector_forward(bp, hp, x, C)
+    for g, w, p in zip(heads, want, pure):
+        e = rel_err(g.cpu().numpy(), w.numpy())
+        e32 = rel_err(g.cpu().numpy(), p.numpy())
+        print("bf16 head %s: vs rounding oracle %.3e, vs fp32 oracle %.3e" % (tuple(g.shape), e, e32))
+        assert e < 1e-2
+        assert e32 < 5e-2
+    # module-by-module path gives the same bits as the planned program
+    s = det.backbone(x.to(DEV))
+    h2 = det.head(*s)
+    for a, b in zip(heads, h2):
+        assert torch.equal(a, b)
+
+
+def test_detector_fp32_end_to_end_detections():
+    """Config 1 geometry (416x416, batch 1, fp32): heads within 1e-3 of the oracle, and
+    decode+filter+NMS of the GPU's heads identical to the oracle's post-processing of
+    those same heads."""
+    from yolo_amd import Detector
+    C = 80
+    for init in ("reference", "variance"):
+        bp, hp = _params(C, init, side=416)
+        x = _image(1, 416)
+        det = Detector(num_classes=C, dtype=torch.float32)
+        det.load_reference_params(bp, hp)
+        det.to(DEV)
+        heads = [h.clone() for h in det.forward_heads(x.to(DEV))]
+        want = N.detector_forward(bp, hp, x, C)
+        for g, w in zip(heads, want):
+            assert rel_err(g.cpu().numpy(), w.numpy()) < 1e-3
+        out = det(x.to(DEV))
+        got = [t.cpu().numpy() for t in out] + [out.keep_idx.cpu().numpy()]
+        heads5 = [h.cpu().numpy().reshape(1, h.shape[1], h.shape[2], 3, 5 + C) for h in heads]
+        if init == "variance":
+            # decoded values differ from the CPU's by ulps; exactness is asserted on identical
+            # decoded inputs in test_gpu_kernels, here the whole chain must agree on the result
+            ref = cref.bbox_nms(heads5, 416.0, C)
+            np.testing.assert_array_equal(got[3], ref[3])
+            np.testing.assert_array_equal(got[4], ref[4])
+            np.testing.assert_allclose(got[0], ref[0], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(got[1], ref[1], rtol=1e-4, atol=1e-7)
+            np.testing.assert_array_equal(got[2], ref[2])
+        else:
+            # reference init: every score ties at ~0.25 = the threshold, so survivors are
+            # decided by the last ulp of a sigmoid; only structural properties are stable
+            assert 0 <= got[3][0] <= 32 and got[0].min() >= 0 and got[0].max() <= 1
+
+
+def test_full_size_determinism_and_batch_invariance():
+    """416x416 bf16: two runs give identical bits; an image's detections do not depend on
+    the batch it is in (what makes the batch-sharded multi-GPU result equal the 1-GPU one)."""
+    from yolo_amd import Detector
+    C = 80
+    bp, hp = _params(C, "variance", side=416)
+    det = Detector(num_classes=C, dtype=torch.bfloat16)
+    det.load_reference_params(bp, hp)
+    det.to(DEV)
+    x = _image(8, 416).to(DEV)
+    a = det(x)
+    a = [t.clone() for t in a] + [a.keep_idx.clone()]
+    heads_a = [h.clone() for h in det.forward_heads(x)]
+    b = det(x)
+    b = [t.clone() for t in b] + [b.keep_idx.clone()]
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert int(a[3].sum()) > 0
+    for i in (0, 5):
+        one = det(x[i:i + 1].contiguous())
+        one = [t.clone() for t in one] + [one.keep_idx.clone()]
+        for u, v in zip(a, one):
+            assert torch.equal(u[i:i + 1], v)
+        h1 = det.forward_heads(x[i:i + 1].contiguous())
+        for u, v in zip(heads_a, h1):
+            assert torch.equal(u[i:i + 1], v)
+
+
+def test_stress_geometry_scaled():
+    """NMS stress geometry (1280^2-equivalent heads, 100 800 candidates, 80 classes,
+    threshold 0.001) at batch 2: decode+filter+NMS vs the C oracle on the GPU's decode."""
+    import yolo_amd as Y
+    from yolo_amd import utils as U
+    C, B = 80, 2
+    gen = torch.Generator().manual_seed(10)
+    heads = []
+    for S in (160, 80, 40):
+        h = torch.randn(B, S, S, 3, 5 + C, generator=gen) * 2
+        h[..., 4] += 6.0
+        heads.append(h.to(DEV))
+    cfg = Y.config
+    dec = U.decode_heads(heads, C, cfg["strides"], cfg["xyscale"], U.default_anchors())
+    n = dec["N"]
+    assert n == 100800
+    d_boxes = dec["boxes"][:, :n].cpu().numpy()
+    d_scores = dec["scores_cm"][:, :, :n].transpose(1, 2).cpu().numpy()
+    fb, fs, counts, src = cref.filter_bboxes(d_boxes, d_scores, 0.001, 1280.0)
+    assert counts.min() > 0.9 * n
+    want = cref.combined_nms(fb, fs, counts, 32, 32, 0.45, 0.001, src_idx=src)
+    raw = [h.reshape(B, h.shape[1], h.shape[2], -1) for h in heads]
+    out = Y.bbox_nms(raw, 1280.0, 32, 32, 0.45, 0.001)
+    got = [t.cpu().numpy() for t in out] + [out.keep_idx.cpu().numpy()]
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-6, atol=1e-7)
+    for a, b in zip(got[1:], want[1:]):
+        np.testing.assert_array_equal(a, b)

@@ -1,0 +1,167 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol the
+header declares, the Python modules mirror the reference's interface, the product path
+refuses to run without a GPU, and the multi-GPU shard/gather logic (gloo, 2 ranks)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ymx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ymx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from yolo_amd import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 17
+    assert sorted(_lib.SIGNATURES) == declared          # the binding covers the header exactly
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert _lib.lib().ymx_version() == 100
+    assert ctypes.sizeof(_lib.ymx_op) == 17 * 4 + 4 + 6 * 8      # 17 ints, padding, 6 pointers
+
+
+def test_argument_validation_without_gpu():
+    """Entry points validate before touching the device, so these run on a CPU-only box."""
+    from yolo_amd import _lib
+    L = _lib.lib()
+    assert L.ymx_packed_weight_bytes(3, 512, 1024, _lib.BF16) == 1024 * 4608 * 2
+    assert L.ymx_packed_weight_bytes(1, 1024, 255, _lib.BF16) == 256 * 1024 * 2
+    assert L.ymx_packed_weight_bytes(3, 32, 64, _lib.F32) == 128 * 320 * 4      # K 288 -> 320
+    assert L.ymx_packed_weight_bytes(3, 3, 32, _lib.BF16) == 27 * 32 * 4        # direct path keeps HWIO fp32
+    assert L.ymx_nms_workspace_bytes(2, 80, 32) == 2 * 80 * 32 * 8 + 640
+    rc = L.ymx_conv2d_fused(None, None, None, None, None, None, 1, 8, 8, 8, 8, 3, 1, 0, 0, None)
+    assert rc == -1 and b"null" in L.ymx_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc)
+    one = ctypes.c_void_p(16)
+    rc = L.ymx_conv2d_fused(one, one, None, None, None, one, 1, 8, 8, 8, 8, 4, 1, 0, 0, None)
+    assert rc == -2 and b"kernel size" in L.ymx_last_error()
+    rc = L.ymx_nms_combined(one, one, None, None, 1, 128, 4, 100, 32, 0.5, 0.1, one, one, one, one, one, one, 1 << 20, None)
+    assert rc == -2
+    rc = L.ymx_nms_combined(one, one, None, None, 1, 128, 4, 32, 32, 0.5, 0.1, one, one, one, one, one, one, 8, None)
+    assert rc == -3
+    with pytest.raises(RuntimeError):
+        _lib.check(rc)
+
+
+def test_module_interface_matches_reference():
+    import yolo_amd
+    from yolo_amd import layers, backbones, detectors
+    assert yolo_amd.config["strides"] == [8, 16, 32] and yolo_amd.config["xyscale"] == [1.2, 1.1, 1.05]
+    assert len(yolo_amd.config["anchors"]) == 18 and yolo_amd.config["anchor_per_scale"] == 3
+    for name in ("decode", "decode_train", "decode_predict", "filter_bboxes", "bbox_nms", "bbox_iou", "bbox_giou"):
+        assert callable(getattr(yolo_amd, name))
+    for name in ("BatchNormalization", "Mish", "RouteGroup", "Upsample", "YOLOConv", "ResidialBlock"):
+        assert hasattr(layers, name)
+    with pytest.raises(ValueError, match="Activation should either be a function"):
+        layers.YOLOConv((3, 3, 8), activation="relu")
+    c = layers.YOLOConv((3, 3, 8), in_channels=4)
+    assert c.kernel.shape == (3, 3, 4, 8) and c.bias.shape == (8,) and c.act_code == 2 and c.bn is None
+    assert abs(float(c.kernel.detach().std()) - 0.01) < 0.003 and float(c.bias.detach().abs().max()) == 0
+    c = layers.YOLOConv((1, 1, 8), batchNormalization=True, activation="leaky", in_channels=4)
+    assert not hasattr(c, "bias") and c.bn is not None and c.act_code == 1
+    assert layers.YOLOConv((3, 3, 8), downsample=True).output_hw(416, 416) == (208, 208)
+
+    bb = backbones.Darknet53()
+    hd = detectors.YoloV3(80)
+    assert len(bb.conv_layers()) == 52 and len(hd.conv_layers()) == 21
+    assert [len(s) for s in (bb.layer_stack_1, bb.layer_stack_2, bb.layer_stack_3)] == [15, 9, 5]
+    n = sum(p.numel() for p in bb.parameters()) + sum(p.numel() for p in hd.parameters())
+    assert n == 88419869
+    assert [c.name for c in hd.conv_layers() if c.name] == ["lbbox", "mbbox", "sbbox"]
+    assert all(c.act_code == 0 and c.filters == 255 for c in hd.conv_layers() if c.name)
+    from oracle import net_torch as N
+    got = [(c.kernel_size, c.in_channels, c.filters, c.downsample) for c in bb.conv_layers() + hd.conv_layers()]
+    want = [(k, ci, co, d) for k, ci, co, d, _ in N.darknet53_specs() + N.yolov3_specs(80)]
+    assert got == want
+
+
+def test_no_cpu_fallback():
+    from yolo_amd import layers, utils
+    x = torch.zeros(1, 8, 8, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layers.YOLOConv((3, 3, 8), in_channels=8)(x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layers.Mish()(x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        utils.bbox_iou(torch.zeros(2, 4), torch.zeros(2, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        utils.bbox_nms([torch.zeros(1, 2, 2, 21), torch.zeros(1, 1, 1, 21)], 16)
+    assert layers.RouteGroup(2, 1)(torch.arange(8.).reshape(1, 1, 1, 8)).flatten().tolist() == [4, 5, 6, 7]
+
+
+def test_product_package_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "yolo_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "oracle/" not in text, f
+
+
+def test_shard_range_and_pack_roundtrip():
+    from yolo_amd import dist as D
+    from yolo_amd.utils import Detections
+    for gb, world in ((256, 8), (10, 4), (3, 8), (64, 1)):
+        spans = [D.shard_range(gb, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == gb
+        for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+            assert s0 + c0 == s1
+        assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    g = torch.Generator().manual_seed(0)
+    det = Detections(torch.rand(3, 5, 4, generator=g), torch.rand(3, 5, generator=g),
+                     torch.randint(0, 80, (3, 5), generator=g).float(),
+                     torch.tensor([5, 0, 2], dtype=torch.int32),
+                     torch.randint(-1, 10647, (3, 5), generator=g, dtype=torch.int32))
+    rec = D.pack_detections(det, 4)
+    assert rec.shape == (4, 36)
+    back = D.unpack_detections(rec[:3], 5)
+    for a, b in zip(tuple(det) + (det.keep_idx,), tuple(back) + (back.keep_idx,)):
+        assert torch.equal(a, b)
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from yolo_amd import dist as D
+from yolo_amd.utils import Detections
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+rank = dist.get_rank()
+GB, T = 5, 4
+g = torch.Generator().manual_seed(7)
+full = Detections(torch.rand(GB, T, 4, generator=g), torch.rand(GB, T, generator=g),
+                  torch.randint(0, 80, (GB, T), generator=g).float(),
+                  torch.randint(0, T + 1, (GB,), generator=g, dtype=torch.int32),
+                  torch.randint(-1, 999, (GB, T), generator=g, dtype=torch.int32))
+s, c = D.shard_range(GB, rank, 2)
+mine = Detections(*[t[s:s + c].clone() for t in full], full.keep_idx[s:s + c].clone())
+got = D.all_gather_detections(mine, GB)
+ok = all(torch.equal(a, b) for a, b in zip(tuple(full) + (full.keep_idx,), tuple(got) + (got.keep_idx,)))
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+"""
+
+
+def test_all_gather_two_ranks_gloo(tmp_path):
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"root": ROOT, "port": port})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)]) for r in range(2)]
+    codes = [p.wait(timeout=120) for p in procs]
+    assert codes == [0, 0]

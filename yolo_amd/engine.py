@@ -47,6 +47,54 @@ class Detector(nn.Module):
         self.head.load_reference_params(head_params)
         self._plans = {}
 
+    @torch.no_grad()
+    def calibrate_(self, x, out_std=2.0, seed=0):
+        """Data-dependent re-scaling of the random parameters (in place).
+
+        The reference's init (N(0, 0.01^2), /root/reference/layers.py:62) drives every
+        activation towards 0 within a few layers, so a randomly initialised detector
+        computes on (near-)zeros.  For benchmarks and tests on random weights this
+        rescales each kernel, layer by layer on the images ``x``, so that its
+        pre-activation has unit standard deviation (0.5 on the second conv of a residual
+        block, ``out_std`` on the three linear output convs) and draws small random
+        biases.  Runs on the GPU through the same kernels as inference.
+        """
+        x = self._check_input(x)
+        gen = torch.Generator().manual_seed(seed)
+
+        def fit(layer, inp, target, residual=None, out_dtype=None):
+            act, layer.act_code = layer.act_code, _lib.ACT_NONE
+            layer.bias.zero_()
+            z = layer(inp, out_dtype=torch.float32 if layer.in_channels % 8 == 0 else None)
+            layer.kernel.mul_(target / float(z.float().std()))
+            layer.act_code = act
+            if act != _lib.ACT_NONE:
+                layer.bias.copy_((0.05 * torch.randn(layer.filters, generator=gen)).to(layer.bias.device))
+            return layer(inp, residual=residual, out_dtype=out_dtype)
+
+        def stack(layers, t):
+            for layer in layers:
+                if isinstance(layer, ResidialBlock):
+                    y = fit(layer.layer_stack[0], t, 1.0)
+                    t = fit(layer.layer_stack[1], y, 0.5, residual=t)
+                else:
+                    t = fit(layer, t, 1.0)
+            return t
+
+        from .layers import upsample2x_concat
+        bb, hd = self.backbone, self.head
+        s1 = stack(bb.layer_stack_1, x)
+        s2 = stack(bb.layer_stack_2, s1)
+        s3 = stack(bb.layer_stack_3, s2)
+        t = stack(hd.layer_stack_1, s3)
+        fit(hd.lbbox_layer_stack[1], fit(hd.lbbox_layer_stack[0], t, 1.0), out_std, out_dtype=hd.out_dtype)
+        t = stack(hd.layer_stack_2, upsample2x_concat(s2, t))
+        fit(hd.mbbox_layer_stack[1], fit(hd.mbbox_layer_stack[0], t, 1.0), out_std, out_dtype=hd.out_dtype)
+        t = stack(list(hd.sbbox_layer_stack)[:-1], upsample2x_concat(s1, t))
+        fit(hd.sbbox_layer_stack[-1], t, out_std, out_dtype=hd.out_dtype)
+        self._plans = {}
+        return self
+
     # ------------------------------------------------------------------ planning
     def _plan(self, B, S, x_dtype, device):
         key = (B, S, x_dtype, str(device))
