@@ -73,6 +73,9 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         if (!aligned16(x) || !aligned16(w)) return fail(YMX_EARG, "conv2d: x and w must be 16-byte aligned");
         if (!aligned16(y) || (residual && !aligned16(residual))) return fail(YMX_EARG, "conv2d: y/residual must be 16-byte aligned");
         a.Kw = packed_kw(k, Cin);
+        const long long xb = (((long long)B * H * W - 1) * a.x_ld + Cin) * (dtype == YMX_BF16 ? 2 : 4);
+        if (xb > 0x80000000LL) return fail(YMX_EUNSUPPORTED, "conv2d: input larger than 2 GiB (%lld bytes)", xb);
+        a.x_bytes = (unsigned)xb;
         return launch_conv_igemm(a, s);
     }
     if (!aligned16(y)) return fail(YMX_EARG, "conv2d: y must be 16-byte aligned");

@@ -71,6 +71,7 @@ struct ConvArgs {
     int Kw;                      // row stride of the packed weights (elements)
     int act;
     int dtype, x_dtype, out_dtype;
+    unsigned x_bytes;            // extent of x in bytes (buffer-load bounds), <= 2^31
 };
 
 // Packed weight geometry, shared by pack and conv.

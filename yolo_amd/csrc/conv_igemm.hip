@@ -17,14 +17,21 @@
 // (64 bf16 or 32 f32).  Both operand tiles are staged through LDS in rows of 128 B,
 // with the 16-byte chunk index XOR-swizzled by (row & 7) so that the ds_write_b128
 // of the staging pass and the ds_read_b128 of the fragment reads are conflict-free.
-// Staging is register-based and split (global loads of step t+1 are issued before
-// the MFMAs of step t, their LDS writes after), double-buffered, one barrier per step.
+//
+// Pipeline: register staging, two LDS buffers, two register sets.  In step t the
+// global loads of tile t+2 are issued first, then the MFMAs of tile t run from LDS,
+// then tile t+1 (loaded during step t-1) is written to the other LDS buffer, then one
+// barrier.  A load therefore has two full steps to land before anything waits for it.
+// Activation loads are raw buffer loads: a lane whose tap falls outside the image
+// (or beyond K) uses an out-of-range offset and the hardware returns zeros, so there
+// is no branch and no select between the load and its use.
 #include "common.h"
 
 namespace ymx {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 template <typename T, typename OT, int TP, int TQ, int WGP>
 __global__ void __launch_bounds__(256, 2)
@@ -36,6 +43,7 @@ conv_igemm_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     constexpr int NI = WQ / 16, NJ = WP / 16;
     constexpr int NXL = TP / 32, NWL = TQ / 32; // 16-byte loads per thread per step
     constexpr int XBYTES = TP * 128, STAGE = (TP + TQ) * 128;
+    constexpr unsigned OOB = 0x80000000u;       // beyond any tensor this kernel accepts
     static_assert(WP % 16 == 0 && WQ % 16 == 0 && NXL >= 1 && NWL >= 1, "tile shape");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -46,8 +54,9 @@ conv_igemm_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int tq = id % ntile_q, tp = id / ntile_q;
     const int p0 = tp * TP, q0 = tq * TQ;
-    const T *__restrict__ x = (const T *)a.x;
     const T *__restrict__ w = (const T *)a.w;
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
 
     // ---- per-thread staging geometry: row (t>>3)+32*i of the tile, chunk t&7 ----
     const int lrow = t >> 3, chunk = t & 7;
@@ -86,21 +95,25 @@ conv_igemm_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     const T *wsrc = w + (size_t)(q0 + lrow) * a.Kw + chunk * KCH;
     const int st_off = lrow * 128 + ((chunk ^ (lrow & 7)) << 4);
 
-    uint4 xr[NXL], wr[NWL];
-    auto gload = [&](int kt) {
+    struct Regs {
+        u32x4_t x[NXL];
+        uint4 w[NWL];
+    };
+    Regs ra, rb;
+
+    auto gload = [&](Regs &r, int kt) {
         const int tapoff = (tr * a.W + tc) * a.x_ld + ci;
-        const bool tapok = tap < 32;
-        const unsigned tapbit = tapok ? (1u << tap) : 0u;
+        const unsigned tapbit = tap < 32 ? (1u << tap) : 0u;
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
             const bool ok = (xmask[i] & tapbit) != 0;
-            const int off = ok ? xoff[i] + tapoff : 0;
-            const uint4 v = *(const uint4 *)(x + off);
-            xr[i] = ok ? v : make_uint4(0, 0, 0, 0);
+            const unsigned off = ok ? (unsigned)(xoff[i] + tapoff) * (unsigned)sizeof(T) : OOB;
+            r.x[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
         }
+        const int ktw = kt < nk ? kt : nk - 1;      // tiles past the end re-read the last column
 #pragma unroll
         for (int i = 0; i < NWL; ++i)
-            wr[i] = *(const uint4 *)(wsrc + (size_t)i * 32 * a.Kw + (size_t)kt * BK);
+            r.w[i] = *(const uint4 *)(wsrc + (size_t)i * 32 * a.Kw + (size_t)ktw * BK);
         ci += BK;
         while (ci >= a.Cin) {
             ci -= a.Cin;
@@ -108,12 +121,12 @@ conv_igemm_kernel(const ConvArgs a, const int ntile_q, const int nk) {
             if (++tc == a.k) { tc = 0; ++tr; }
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const Regs &r, int buf) {
         char *xs = smem + buf * STAGE + st_off;
 #pragma unroll
-        for (int i = 0; i < NXL; ++i) *(uint4 *)(xs + i * 4096) = xr[i];
+        for (int i = 0; i < NXL; ++i) *(u32x4_t *)(xs + i * 4096) = r.x[i];
 #pragma unroll
-        for (int i = 0; i < NWL; ++i) *(uint4 *)(xs + XBYTES + i * 4096) = wr[i];
+        for (int i = 0; i < NWL; ++i) *(uint4 *)(xs + XBYTES + i * 4096) = r.w[i];
     };
 
     f32x4_t acc[NI][NJ];
@@ -127,15 +140,8 @@ conv_igemm_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     const int swz0 = (((lane >> 4)) ^ (lane & 7)) << 4;
     const int swz1 = ((4 + (lane >> 4)) ^ (lane & 7)) << 4;
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) gload(kt + 1);
-        const char *base = smem + cur * STAGE;
+    auto compute = [&](int buf) {
+        const char *base = smem + buf * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int swz = kk ? swz1 : swz0;
@@ -164,9 +170,29 @@ conv_igemm_kernel(const ConvArgs a, const int ntile_q, const int nk) {
                     }
                 }
         }
-        if (more) lstore(cur ^ 1);
+    };
+    // One pipeline step: tile kt is in LDS buffer kt&1, tile kt+1 in `next`, `far` is free.
+    // Every step issues the same loads and stores, needed or not (tiles past the end
+    // read zeros / a clamped weight column and land in an LDS buffer nobody reads), so
+    // the number of loads in flight at each wait is a compile-time constant and the
+    // compiler can wait for exactly the older register set.
+    auto step = [&](Regs &far, const Regs &next, int kt) {
+        gload(far, kt + 2);
+        compute(kt & 1);
+        lstore(next, (kt & 1) ^ 1);
         __syncthreads();
+    };
+
+    gload(ra, 0);
+    gload(rb, 1);
+    lstore(ra, 0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        step(ra, rb, kt);
+        step(rb, ra, kt + 1);
     }
+    if (kt < nk) compute(kt & 1);
 
     // ---- epilogue: scale/shift, activation, shortcut, store ----------------------
     OT *__restrict__ y = (OT *)a.y;
