@@ -41,6 +41,13 @@ enum {
 int ymx_version(void);
 const char *ymx_last_error(void);
 
+/* Process-wide tuning knobs (no counterpart in the reference).  "dma_min_tiles": the
+ * fewest 256x256 output tiles for which a bf16 convolution with more than 128 output
+ * channels runs on the large-tile LDS-DMA kernel instead of the 128x128 kernel
+ * (default 160; 0 forces it, a huge value disables it).  Results do not depend on it
+ * beyond fp32 summation order. */
+int ymx_set_option(const char *name, long long value);
+
 /* ---- convolution block ------------------------------------------------------
  * Replaces YOLOConv.call — layers.py:86-90 with the stack built at layers.py:46-81
  * ([ZeroPadding2D top/left] -> Conv2D -> [BatchNormalization] -> [Mish|LeakyReLU])

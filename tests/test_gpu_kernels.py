@@ -130,6 +130,50 @@ def test_conv_plain_entry_point_and_strides():
     assert torch.equal(yw[..., 8:40], y) and bool((yw[..., :8] == 7).all()) and bool((yw[..., 40:] == 7).all())
 
 
+DMA_SHAPES = [
+    # B, H, W, Cin, Cout, k, down, act, residual     (all routed to the large-tile LDS-DMA kernel)
+    (2, 13, 13, 64, 255, 1, False, None, False),        # one partial channel tile, ragged pixels
+    (1, 13, 13, 512, 1024, 3, False, "mish", True),      # K = 4608, 4 channel tiles
+    (3, 20, 20, 128, 256, 3, True, "mish", False),       # stride 2, padding on top/left only
+    (2, 26, 26, 768, 512, 1, False, "leaky", False),     # Cin not a power of two
+    (1, 9, 11, 32, 384, 3, False, "mish", True),         # Cin 32 (two taps per K step), 1.5 tiles
+    (1, 33, 31, 8, 200, 5, False, None, False),          # 5x5, Cin 8, several pixel tiles
+]
+
+
+@pytest.mark.parametrize("case", range(len(DMA_SHAPES)))
+def test_conv_dma_kernel_forced(case):
+    """The 256-pixel x 256-channel LDS-DMA kernel on shapes it would not normally be
+    picked for (dma_min_tiles = 0), bf16 and fp32 outputs, against the oracle and against
+    the 128x128 kernel (same summation order: identical bits)."""
+    from yolo_amd import _lib
+    B, H, W, cin, cout, k, down, act, use_res = DMA_SHAPES[case]
+    g = torch.Generator().manual_seed(300 + case)
+    x = N.bf16_round(torch.randn(B, H, W, cin, generator=g))
+    p = {"kernel": N.bf16_round(torch.randn(k, k, cin, cout, generator=g) * (2.0 / (k * k * cin)) ** 0.5),
+         "bias": 0.1 * torch.randn(cout, generator=g)}
+    want = N.yolo_conv(x, p, down, act)
+    res = None
+    if use_res:
+        res = N.bf16_round(torch.randn(*want.shape, generator=g))
+        want = want + res
+    layer = make_conv(p, k, down, act, False, torch.bfloat16)
+    xin = x.to(DEV).bfloat16()
+    rin = None if res is None else res.to(DEV).bfloat16()
+    L = _lib.lib()
+    try:
+        _lib.check(L.ymx_set_option(b"dma_min_tiles", 1 << 40))
+        y_small = layer(xin, residual=rin)
+        _lib.check(L.ymx_set_option(b"dma_min_tiles", 0))
+        y = layer(xin, residual=rin)
+        y32 = layer(xin, residual=rin, out_dtype=torch.float32)
+    finally:
+        _lib.check(L.ymx_set_option(b"dma_min_tiles", 160))
+    assert rel_err(y.float().cpu().numpy(), want.numpy()) < 1e-2
+    assert rel_err(y32.cpu().numpy(), want.numpy()) < 1e-3
+    assert torch.equal(y, y_small)
+
+
 def test_layers_standalone():
     from yolo_amd import layers
     g = torch.Generator().manual_seed(2)

@@ -29,6 +29,7 @@ class ymx_op(ctypes.Structure):
 SIGNATURES = {
     "ymx_version": (_i, []),
     "ymx_last_error": (ctypes.c_char_p, []),
+    "ymx_set_option": (_i, [ctypes.c_char_p, _ll]),
     "ymx_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "ymx_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ymx_conv2d_fused": (_i, [_vp] * 6 + [_i] * 9 + [_vp]),

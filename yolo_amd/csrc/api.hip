@@ -3,6 +3,7 @@
 // runtime calls besides launches are hipMemsetAsync on caller-provided workspace.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -30,6 +31,18 @@ int check_launch(const char *what) {
 }
 
 static bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+// Fewest 256x256 tiles for which the large-tile kernel is chosen (one workgroup per CU,
+// 256 CUs).  YMX_DMA_MIN_TILES overrides it for experiments (a huge value disables the
+// kernel, 0 forces it).
+static long long g_dma_min_tiles = -1;
+static long long dma_min_tiles() {
+    if (g_dma_min_tiles < 0) {
+        const char *e = getenv("YMX_DMA_MIN_TILES");
+        g_dma_min_tiles = e ? atoll(e) : 160;
+    }
+    return g_dma_min_tiles;
+}
 
 static int conv_impl(const void *x, const void *w, const void *scale, const void *shift,
                      const void *residual, void *y, int B, int H, int W, int Cin, int Cout, int k,
@@ -76,6 +89,13 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         const long long xb = (((long long)B * H * W - 1) * a.x_ld + Cin) * (dtype == YMX_BF16 ? 2 : 4);
         if (xb > 0x80000000LL) return fail(YMX_EUNSUPPORTED, "conv2d: input larger than 2 GiB (%lld bytes)", xb);
         a.x_bytes = (unsigned)xb;
+        a.w_bytes = (unsigned)((size_t)packed_rows(Cout) * a.Kw * (dtype == YMX_BF16 ? 2 : 4));
+        // Large-tile LDS-DMA kernel when the layer is wide enough to fill 256-channel tiles
+        // and has enough of them to occupy the chip; the 128x128 kernel otherwise.
+        if (dtype == YMX_BF16 && Cout > 128) {
+            const long long tiles = ((long long)(a.P + 255) / 256) * ((Cout + 255) / 256);
+            if (tiles >= dma_min_tiles()) return launch_conv_igemm_dma(a, s);
+        }
         return launch_conv_igemm(a, s);
     }
     if (!aligned16(y)) return fail(YMX_EARG, "conv2d: y must be 16-byte aligned");
@@ -90,6 +110,16 @@ using namespace ymx;
 extern "C" {
 
 int ymx_version(void) { return YMX_VERSION; }
+
+int ymx_set_option(const char *name, long long value) {
+    if (!name) return fail(YMX_EARG, "set_option: null name");
+    if (!strcmp(name, "dma_min_tiles")) {
+        if (value < 0) return fail(YMX_EARG, "set_option: dma_min_tiles must be >= 0");
+        g_dma_min_tiles = value;
+        return YMX_OK;
+    }
+    return fail(YMX_EARG, "set_option: unknown option '%s'", name);
+}
 const char *ymx_last_error(void) { return g_err.c_str(); }
 
 size_t ymx_packed_weight_bytes(int k, int Cin, int Cout, int dtype) {

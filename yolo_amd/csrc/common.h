@@ -72,6 +72,7 @@ struct ConvArgs {
     int act;
     int dtype, x_dtype, out_dtype;
     unsigned x_bytes;            // extent of x in bytes (buffer-load bounds), <= 2^31
+    unsigned w_bytes;            // extent of the packed weights in bytes
 };
 
 // Packed weight geometry, shared by pack and conv.
@@ -82,6 +83,7 @@ static inline int packed_kw(int k, int Cin) { return ((k * k * Cin + 63) / 64) *
 static inline int packed_rows(int Cout) { return ((Cout + 127) / 128) * 128; }
 
 int launch_conv_igemm(const ConvArgs &a, hipStream_t s);
+int launch_conv_igemm_dma(const ConvArgs &a, hipStream_t s);
 int launch_conv_direct(const ConvArgs &a, hipStream_t s);
 int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype,
                         hipStream_t s);

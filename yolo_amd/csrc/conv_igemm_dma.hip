@@ -1,0 +1,258 @@
+// Large-tile bf16 implicit-GEMM convolution with LDS-DMA staging (gfx950).
+//
+// Same mathematics and operand orientation as conv_igemm.hip (weights as the MFMA A
+// operand, pixels as B, D[row = channel][col = pixel]); what differs is the data path:
+//
+//  - a workgroup of 8 waves (512 threads) owns a 256-pixel x TQ-channel tile (TQ = 256 or
+//    128), so every byte staged from L2 feeds twice as many MFMAs as in the 128x128
+//    kernel, whose staging traffic (64 B/clk/CU at full MFMA rate) sits on the CU's
+//    L1 bandwidth;
+//  - tiles go global -> LDS directly with `buffer_load_dwordx4 ... lds` (no VGPR
+//    staging, no ds_write pass).  The LDS image of one wave-instruction is linear
+//    (M0 base + lane*16 B = 8 rows x 128 B); the XOR swizzle that keeps the ds_read_b128
+//    fragment reads conflict-free is applied on the SOURCE side: the lane that fills
+//    slot s of row r fetches K-chunk s ^ (r & 7).  A lane whose tap is outside the image
+//    (zero padding) or beyond K uses an out-of-range buffer offset, for which the
+//    hardware writes zeros into LDS: padding costs no branch and no memory traffic;
+//  - two LDS stages of (256 + TQ) x 128 B; the DMA of tile t+1 is issued before the
+//    MFMAs of tile t and waited for (vmcnt(0)) after them, one barrier per K step.
+#include "common.h"
+
+namespace ymx {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+// 128-bit raw buffer descriptor (base, stride 0, byte extent) held in SGPRs.
+__device__ __forceinline__ i32x4_t make_rsrc(const void *p, unsigned bytes) {
+    const unsigned long long addr = (unsigned long long)p;
+    i32x4_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(addr & 0xffffffffull));
+    r[1] = __builtin_amdgcn_readfirstlane((int)((addr >> 32) & 0xffffull));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = __builtin_amdgcn_readfirstlane(0x00020000);
+    return r;
+}
+
+// One LDS-DMA wave-instruction: lane l's 16 bytes at buffer offset `voff` land at LDS byte
+// address lds_addr + 16*l (zeros if voff is out of range).  Written as inline asm on
+// purpose: the compiler neither counts it in vmcnt nor orders LDS reads behind it, so
+// the transfer overlaps the MFMAs that follow; the caller waits (vmcnt) and then
+// barriers before any wave reads the bytes.  M0 carries the LDS base and is restored.
+__device__ __forceinline__ void lds_dma16(const i32x4_t rsrc, unsigned lds_addr, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 4\n\t"
+                 "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_addr), "s"(rsrc)
+                 : "memory");
+}
+
+template <typename OT, int TQ>
+__global__ void __launch_bounds__(512, 2)
+conv_igemm_dma_kernel(const ConvArgs a, const int ntile_q, const int nk) {
+    constexpr int TP = 256;
+    constexpr int WGQ = TQ / 128, WGP = 8 / WGQ;        // wave grid: channels x pixels
+    constexpr int WQ = 128, WP = TP / WGP;              // wave tile
+    constexpr int NI = WQ / 16, NJ = WP / 16;
+    constexpr int NXI = TP / 64, NWI = TQ / 64;         // DMA instructions per wave per step
+    constexpr int XBYTES = TP * 128, STAGE = (TP + TQ) * 128;
+    constexpr unsigned OOB = 0x80000000u;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wq = wave % WGQ, wp = wave / WGQ;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tq = id % ntile_q, tp = id / ntile_q;
+    const int p0 = tp * TP, q0 = tq * TQ;
+    const i32x4_t xrsrc = make_rsrc(a.x, a.x_bytes);
+    const i32x4_t wrsrc = make_rsrc(a.w, a.w_bytes);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+
+    // ---- DMA geometry: instruction i of this wave fills rows 8*(wave*N + i) .. +7 ----
+    const int srow = lane >> 3;                         // row inside an 8-row piece
+    const int chunk = (lane & 7) ^ (srow & 7);          // K-chunk this lane fetches (swizzle)
+    int xoff[NXI];
+    unsigned xmask[NXI];
+    {
+        const int ohw = a.OH * a.OW;
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const int p = p0 + (wave * NXI + i) * 8 + srow;
+            int off = 0;
+            unsigned m = 0;
+            if (p < a.P) {
+                const int b = p / ohw, rem = p - b * ohw;
+                const int oh = rem / a.OW, ow = rem - oh * a.OW;
+                const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
+                off = ((b * a.H + ih0) * a.W + iw0) * a.x_ld;
+                for (int r = 0; r < a.k; ++r)
+                    for (int c = 0; c < a.k; ++c) {
+                        const bool ok = (unsigned)(ih0 + r) < (unsigned)a.H &&
+                                        (unsigned)(iw0 + c) < (unsigned)a.W;
+                        m |= (ok ? 1u : 0u) << (r * a.k + c);
+                    }
+            }
+            xoff[i] = off;
+            xmask[i] = m;
+        }
+    }
+    int ci = chunk * 8, tap = 0, tr = 0, tc = 0;
+    while (ci >= a.Cin) {
+        ci -= a.Cin;
+        ++tap;
+        if (++tc == a.k) { tc = 0; ++tr; }
+    }
+    // byte offset of this lane's weight chunk in tile 0, piece 0 of this wave
+    const unsigned woff0 = (unsigned)(((q0 + wave * NWI * 8 + srow) * a.Kw + chunk * 8) * 2);
+    const unsigned wpiece = (unsigned)(8 * a.Kw * 2);
+
+    auto dma = [&](int kt, int stage) {
+        const unsigned sbase = lds0 + (unsigned)(stage * STAGE);
+        const int tapoff = (tr * a.W + tc) * a.x_ld + ci;
+        const unsigned tapbit = tap < 32 ? (1u << tap) : 0u;
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const bool ok = (xmask[i] & tapbit) != 0;
+            const unsigned off = ok ? (unsigned)(xoff[i] + tapoff) * 2u : OOB;
+            lds_dma16(xrsrc, sbase + (unsigned)((wave * NXI + i) * 1024), off);
+        }
+#pragma unroll
+        for (int i = 0; i < NWI; ++i)
+            lds_dma16(wrsrc, sbase + (unsigned)(XBYTES + (wave * NWI + i) * 1024),
+                      woff0 + (unsigned)i * wpiece + (unsigned)kt * 128u);
+        ci += 64;
+        while (ci >= a.Cin) {
+            ci -= a.Cin;
+            ++tap;
+            if (++tc == a.k) { tc = 0; ++tr; }
+        }
+    };
+
+    f32x4_t acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int a_off = XBYTES + (wq * WQ + (lane & 15)) * 128;
+    const int b_off = (wp * WP + (lane & 15)) * 128;
+    const int swz0 = (((lane >> 4)) ^ (lane & 7)) << 4;
+    const int swz1 = ((4 + (lane >> 4)) ^ (lane & 7)) << 4;
+
+    auto compute = [&](int stage) {
+        const char *base = smem + stage * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int swz = kk ? swz1 : swz0;
+            uint4 af[NI], bfr[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bfr[j] = *(const uint4 *)(base + b_off + j * 2048 + swz);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) af[i] = *(const uint4 *)(base + a_off + i * 2048 + swz);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+        }
+    };
+
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) dma(kt + 1, (kt + 1) & 1);
+        compute(kt & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: scale/shift, activation, shortcut, store ----------------------
+    OT *__restrict__ y = (OT *)a.y;
+    const bf16_t *__restrict__ res = (const bf16_t *)a.res;
+    const bool vec_ok = ((a.Cout & 3) == 0) && ((a.y_ld & 3) == 0) && (res == nullptr || (a.res_ld & 3) == 0);
+    const int co_base = q0 + wq * WQ + 4 * (lane >> 4);
+    const int px_base = p0 + wp * WP + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int co = co_base + i * 16;
+        float sc[4], sh[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = co + r;
+            const bool in = c < a.Cout;
+            sc[r] = in ? (a.scale ? a.scale[c] : 1.0f) : 0.0f;
+            sh[r] = (in && a.shift) ? a.shift[c] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int p = px_base + j * 16;
+            if (p >= a.P || co >= a.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_f(acc[i][j][r] * sc[r] + sh[r], a.act);
+            if (vec_ok) {
+                if (res) {
+                    const uint2 rv = *(const uint2 *)(res + (size_t)p * a.res_ld + co);
+                    v[0] += __uint_as_float(rv.x << 16);
+                    v[1] += __uint_as_float(rv.x & 0xffff0000u);
+                    v[2] += __uint_as_float(rv.y << 16);
+                    v[3] += __uint_as_float(rv.y & 0xffff0000u);
+                }
+                OT *yp = y + (size_t)p * a.y_ld + co;
+                if constexpr (sizeof(OT) == 2) {
+                    *(uint2 *)yp = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+                } else {
+                    *(float4 *)yp = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (co + r < a.Cout) {
+                        float o = v[r];
+                        if (res) o += bf16_to_f32(res[(size_t)p * a.res_ld + co + r]);
+                        elem<OT>::store(y + (size_t)p * a.y_ld + co + r, o);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename OT, int TQ>
+static int launch_dma_cfg(const ConvArgs &a, hipStream_t s) {
+    constexpr int LDS = 2 * (256 + TQ) * 128;
+    auto kern = conv_igemm_dma_kernel<OT, TQ>;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(YMX_ELAUNCH, "conv_igemm_dma: cannot reserve %d bytes of LDS", LDS);
+        }
+        configured = true;
+    }
+    const int ntile_p = (a.P + 255) / 256;
+    const int ntile_q = (a.Cout + TQ - 1) / TQ;
+    const int nk = (a.K + 63) / 64;
+    const long long grid = (long long)ntile_p * ntile_q;
+    if (grid > 0x7fffffffLL) return fail(YMX_EUNSUPPORTED, "conv_igemm_dma: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, a, ntile_q, nk);
+    return check_launch("conv_igemm_dma");
+}
+
+// bf16 operands only; out_dtype bf16 or f32.
+int launch_conv_igemm_dma(const ConvArgs &a, hipStream_t s) {
+    if (a.dtype != YMX_BF16) return fail(YMX_EUNSUPPORTED, "conv_igemm_dma: bf16 operands only");
+    if (a.out_dtype == YMX_BF16) return launch_dma_cfg<bf16_t, 256>(a, s);
+    return launch_dma_cfg<float, 256>(a, s);
+}
+
+}  // namespace ymx
