@@ -44,12 +44,15 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
-// x * tanh(softplus(x)) with one exp:  tanh(log(1+e)) = (e^2+2e)/(e^2+2e+2).
+// x * tanh(softplus(x)) with one exp and one reciprocal:
+//   tanh(log(1+e)) = n/(n+2),  n = e*(e+2),  e = exp(x).
+// v_exp_f32 and v_rcp_f32 are 1-ulp instructions; the clamp keeps n finite (for
+// x >= 20 the ratio is 1 to fp32 precision, so the result is x), and the product form
+// keeps full relative accuracy for very negative x, where the result is ~ x*e^x.
 __device__ __forceinline__ float mish_f(float x) {
-    const float e = __expf(fminf(x, 20.0f));
+    const float e = __builtin_amdgcn_exp2f(fminf(x, 20.0f) * 1.44269504088896f);
     const float n = e * (e + 2.0f);
-    const float m = x * (n / (n + 2.0f));
-    return x > 20.0f ? x : m;
+    return x * (n * __builtin_amdgcn_rcpf(n + 2.0f));
 }
 __device__ __forceinline__ float act_f(float v, int act) {
     if (act == YMX_ACT_MISH) return mish_f(v);

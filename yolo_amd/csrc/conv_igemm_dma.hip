@@ -146,78 +146,135 @@ conv_igemm_dma_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     const int swz0 = (((lane >> 4)) ^ (lane & 7)) << 4;
     const int swz1 = ((4 + (lane >> 4)) ^ (lane & 7)) << 4;
 
-    auto compute = [&](int stage) {
-        const char *base = smem + stage * STAGE;
+    // One K step.  The wave's MFMA work is cut into NI segments (one 16-channel row of
+    // its tile each: 2*NJ MFMAs); the DMA pieces of the next tile are issued one X and
+    // one W piece per segment in the first segments (so the last piece still has half a
+    // step to land), and the A fragments of segment i+1 are read from LDS before the
+    // MFMAs of segment i.  With two waves per SIMD the issue work of one wave then runs
+    // under the MFMAs of the other instead of both queueing for the matrix pipe at once.
+    auto step = [&](int kt) {
+        const char *base = smem + (kt & 1) * STAGE;
+        const bool more = kt + 1 < nk;
+        const unsigned sbase = lds0 + (unsigned)(((kt + 1) & 1) * STAGE);
+        const int tapoff = (tr * a.W + tc) * a.x_ld + ci;
+        const unsigned tapbit = tap < 32 ? (1u << tap) : 0u;
+        const unsigned wstep = woff0 + (unsigned)(kt + 1) * 128u;
+
+        uint4 bfr[2][NJ], af[2][2];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int swz = kk ? swz1 : swz0;
-            uint4 af[NI], bfr[NJ];
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) bfr[j] = *(const uint4 *)(base + b_off + j * 2048 + swz);
+            for (int j = 0; j < NJ; ++j) bfr[kk][j] = *(const uint4 *)(base + b_off + j * 2048 + (kk ? swz1 : swz0));
+        af[0][0] = *(const uint4 *)(base + a_off + swz0);
+        af[0][1] = *(const uint4 *)(base + a_off + swz1);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) af[i] = *(const uint4 *)(base + a_off + i * 2048 + swz);
+        for (int i = 0; i < NI; ++i) {
+            if (i + 1 < NI) {
+                af[(i + 1) & 1][0] = *(const uint4 *)(base + a_off + (i + 1) * 2048 + swz0);
+                af[(i + 1) & 1][1] = *(const uint4 *)(base + a_off + (i + 1) * 2048 + swz1);
+            }
+            if (more) {
+                if (i < NXI) {
+                    const bool ok = (xmask[i] & tapbit) != 0;
+                    const unsigned off = ok ? (unsigned)(xoff[i] + tapoff) * 2u : OOB;
+                    lds_dma16(xrsrc, sbase + (unsigned)((wave * NXI + i) * 1024), off);
+                }
+                if (i < NWI)
+                    lds_dma16(wrsrc, sbase + (unsigned)(XBYTES + (wave * NWI + i) * 1024), wstep + (unsigned)i * wpiece);
+            }
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+                        __builtin_bit_cast(bf16x8_t, af[i & 1][kk]), __builtin_bit_cast(bf16x8_t, bfr[kk][j]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
+        ci += 64;
+        while (ci >= a.Cin) {
+            ci -= a.Cin;
+            ++tap;
+            if (++tc == a.k) { tc = 0; ++tr; }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     };
 
     dma(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) dma(kt + 1, (kt + 1) & 1);
-        compute(kt & 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
+    for (int kt = 0; kt < nk; ++kt) step(kt);
 
-    // ---- epilogue: scale/shift, activation, shortcut, store ----------------------
+    // ---- epilogue -------------------------------------------------------------------
+    // In the accumulator layout a lane owns 4 channels of one pixel per 16x16 tile, so a
+    // direct store touches 16 pixel rows with 32 contiguous bytes each.  LDS is free
+    // now, so every wave transposes its own tile privately (no workgroup barrier): per
+    // 64-channel half it writes act(acc*scale+shift) as fp32 rows [pixel][64 channels]
+    // (16-byte slots XOR-swizzled by the pixel index: conflict-free both ways), then
+    // reads them back with 16 lanes per pixel, adds the shortcut (loaded in the same
+    // pattern), rounds once and stores: 128 contiguous bytes per pixel per instruction.
     OT *__restrict__ y = (OT *)a.y;
     const bf16_t *__restrict__ res = (const bf16_t *)a.res;
     const bool vec_ok = ((a.Cout & 3) == 0) && ((a.y_ld & 3) == 0) && (res == nullptr || (a.res_ld & 3) == 0);
-    const int co_base = q0 + wq * WQ + 4 * (lane >> 4);
-    const int px_base = p0 + wp * WP + (lane & 15);
+    static_assert(8 * WP * 256 <= 2 * STAGE, "per-wave transpose images must fit in LDS");
+    char *tbase = smem + wave * (WP * 256);
+    const int act = a.act;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int co = co_base + i * 16;
-        float sc[4], sh[4];
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = co + r;
-            const bool in = c < a.Cout;
-            sc[r] = in ? (a.scale ? a.scale[c] : 1.0f) : 0.0f;
-            sh[r] = (in && a.shift) ? a.shift[c] : 0.0f;
+        for (int il = 0; il < NI / 2; ++il) {
+            const int i = half * (NI / 2) + il;
+            const int co = q0 + wq * WQ + i * 16 + 4 * (lane >> 4);
+            float sc[4], sh[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = co + r;
+                const bool in = c < a.Cout;
+                sc[r] = in ? (a.scale ? a.scale[c] : 1.0f) : 0.0f;
+                sh[r] = (in && a.shift) ? a.shift[c] : 0.0f;
+            }
+            const int slot = il * 4 + (lane >> 4);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float4 v;
+                v.x = act_f(acc[i][j][0] * sc[0] + sh[0], act);
+                v.y = act_f(acc[i][j][1] * sc[1] + sh[1], act);
+                v.z = act_f(acc[i][j][2] * sc[2] + sh[2], act);
+                v.w = act_f(acc[i][j][3] * sc[3] + sh[3], act);
+                const int px = j * 16 + (lane & 15);
+                *(float4 *)(tbase + px * 256 + ((slot ^ (px & 15)) << 4)) = v;
+            }
         }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int p = px_base + j * 16;
+        // rows back out: lane -> pixel 4n + (lane >> 4), channels 4*(lane & 15) .. +3 of this half
+        const int slot = lane & 15;
+        const int co = q0 + wq * WQ + half * (WQ / 2) + slot * 4;
+#pragma unroll 4
+        for (int n = 0; n < WP / 4; ++n) {
+            const int px = n * 4 + (lane >> 4);
+            const int p = p0 + wp * WP + px;
+            float4 v = *(const float4 *)(tbase + px * 256 + ((slot ^ (px & 15)) << 4));
             if (p >= a.P || co >= a.Cout) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_f(acc[i][j][r] * sc[r] + sh[r], a.act);
             if (vec_ok) {
                 if (res) {
                     const uint2 rv = *(const uint2 *)(res + (size_t)p * a.res_ld + co);
-                    v[0] += __uint_as_float(rv.x << 16);
-                    v[1] += __uint_as_float(rv.x & 0xffff0000u);
-                    v[2] += __uint_as_float(rv.y << 16);
-                    v[3] += __uint_as_float(rv.y & 0xffff0000u);
+                    v.x += __uint_as_float(rv.x << 16);
+                    v.y += __uint_as_float(rv.x & 0xffff0000u);
+                    v.z += __uint_as_float(rv.y << 16);
+                    v.w += __uint_as_float(rv.y & 0xffff0000u);
                 }
                 OT *yp = y + (size_t)p * a.y_ld + co;
                 if constexpr (sizeof(OT) == 2) {
-                    *(uint2 *)yp = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+                    *(uint2 *)yp = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
                 } else {
-                    *(float4 *)yp = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4 *)yp = v;
                 }
             } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (co + r < a.Cout) {
-                        float o = v[r];
+                        float o = vv[r];
                         if (res) o += bf16_to_f32(res[(size_t)p * a.res_ld + co + r]);
                         elem<OT>::store(y + (size_t)p * a.y_ld + co + r, o);
                     }
