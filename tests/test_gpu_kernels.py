@@ -72,6 +72,8 @@ CONV_SHAPES = [
     (3, 7, 9, 8, 24, 3, False, "mish", False, False),        # smallest MFMA-eligible channels (bf16)
     (1, 11, 11, 16, 48, 5, False, None, False, False),       # 5x5
     (1, 9, 9, 3, 20, 3, True, "mish", False, False),         # direct path, odd sizes, downsample
+    (3, 9, 7, 3, 32, 3, False, "mish", False, False),        # first-layer shape (MFMA gather kernel in bf16)
+    (2, 37, 41, 3, 32, 3, False, "leaky", False, True),      # same, several 64-pixel chunks, folded BN
 ]
 
 

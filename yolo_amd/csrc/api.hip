@@ -100,6 +100,12 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
     }
     if (!aligned16(y)) return fail(YMX_EARG, "conv2d: y must be 16-byte aligned");
     a.Kw = Cout;
+    {
+        // extent of x for the bounds-checked loads of the first-layer kernel (0 = unknown:
+        // inputs beyond 2 GiB fall back to the plain direct kernel)
+        const long long xb = (((long long)B * H * W - 1) * a.x_ld + Cin) * (x_dtype == YMX_BF16 ? 2 : 4);
+        a.x_bytes = (xb <= 0x80000000LL && aligned16(x)) ? (unsigned)xb : 0u;
+    }
     return launch_conv_direct(a, s);
 }
 

@@ -79,7 +79,208 @@ conv_direct_kernel(const ConvArgs a) {
     }
 }
 
+// ---- first layer on MFMA: 3x3, Cin = 3, Cout = 32, stride 1, bf16 network ----------
+// K = 27 fits one mfma_f32_16x16x32_bf16 (5 zero columns).  The 27 inputs of a pixel are
+// three runs of 9 contiguous values (3 pixels x 3 channels of one image row), so the
+// pixel operand is gathered straight from global memory: lane (pixel lane&15, k-group
+// lane>>4) loads k = 8g .. 8g+7, converts to bf16 and packs.  Weights are the A operand
+// and stay in registers for the whole kernel; output row i of channel tile t holds
+// channel 8*(i>>2) + 4*t + (i&3), so after both tiles a lane owns 8 consecutive channels
+// of its pixel and the epilogue (bias, activation) ends in one 16-byte store per pixel.
+// The layer writes 64 B per pixel for 27 MACs per channel: it is HBM-bound (709 MB per
+// batch-64 step at 416x416), and the gather costs ~1/8 of the VALU work of the scalar form.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_first_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_first_t;
+
+template <typename XT>
+__global__ void __launch_bounds__(256)
+conv_first_mfma_kernel(const ConvArgs a, const int nchunk) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, li = lane & 15;
+    const XT *__restrict__ x = (const XT *)a.x;
+    const float *__restrict__ w = (const float *)a.w;          // [27][32] fp32 (HWIO)
+    bf16_t *__restrict__ y = (bf16_t *)a.y;
+
+    // A fragments: tile t, row li -> channel 8*(li>>2) + 4t + (li&3); k = 8g + j
+    bf16x8_first_t af[2];
+    int koff[8];            // element offset of k = 8g+j relative to the pixel's (b, oh, ow, 0)
+    int kdr[8], kdc[8];     // row / column displacement of that tap; a huge kdr marks k >= 27
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * g + j;
+        const int r = k / 9, c = (k - 9 * r) / 3, ci = k - 9 * r - 3 * c;
+        const bool kin = k < 27;
+        kdr[j] = kin ? r - 1 : (1 << 28);
+        kdc[j] = c - 1;
+        koff[j] = ((r - 1) * a.W + (c - 1)) * a.x_ld + ci;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ch = 8 * (li >> 2) + 4 * t + (li & 3);
+            af[t][j] = (__bf16)(kin ? w[k * 32 + ch] : 0.0f);
+        }
+    }
+    float sc[8], sh[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        sc[r] = a.scale ? a.scale[8 * g + r] : 1.0f;
+        sh[r] = a.shift ? a.shift[8 * g + r] : 0.0f;
+    }
+    const int hw = a.OH * a.OW;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    for (int chunk = wave_global; chunk < nchunk; chunk += nwaves) {
+        // 64 pixels per wave per iteration: four 16-pixel B fragments
+        bf16x8_first_t bf[4];
+        int pix[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int p = chunk * 64 + f * 16 + li;
+            pix[f] = p;
+            const int pp = p < a.P ? p : a.P - 1;
+            const int b = pp / hw, rem = pp - b * hw;
+            const int oh = rem / a.OW, ow = rem - oh * a.OW;
+            const XT *base = x + ((size_t)(b * a.H + oh) * a.W + ow) * a.x_ld;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = (unsigned)(oh + kdr[j]) < (unsigned)a.H && (unsigned)(ow + kdc[j]) < (unsigned)a.W;
+                const float v = ok ? elem<XT>::load(base + koff[j]) : 0.0f;
+                bf[f][j] = (__bf16)v;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            f32x4_first_t d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[f], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[f], d1, 0, 0, 0);
+            if (pix[f] < a.P) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = act_f(d0[r] * sc[r] + sh[r], a.act);
+                    v[4 + r] = act_f(d1[r] * sc[4 + r] + sh[4 + r], a.act);
+                }
+                *(uint4 *)(y + (size_t)pix[f] * a.y_ld + 8 * g) =
+                    make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+            }
+        }
+    }
+}
+
+// Same layer, fp32 image, one wave per 64-pixel run of one output row.  All pixel index
+// arithmetic is per wave (no per-lane division).  The K axis is re-ordered so that every
+// lane's operand is one contiguous run of the image: k-group g = tap row g holds the first
+// 8 of that row's 9 values (3 pixels x 3 channels), loaded as two 16-byte buffer loads
+// (out-of-range offsets return zeros); the 9th value of each row goes to a second MFMA
+// (slot 0 of group g).  Weights are permuted to match when the A fragments are built.
+template <int DUMMY>
+__global__ void __launch_bounds__(256)
+conv_first_rows_kernel(const ConvArgs a, const int chunks_per_row, const int nchunk) {
+    typedef __attribute__((ext_vector_type(4))) float f4;
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, li = lane & 15;
+    const float *__restrict__ w = (const float *)a.w;          // [27][32] fp32 (HWIO)
+    bf16_t *__restrict__ y = (bf16_t *)a.y;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+
+    bf16x8_first_t a1[2], a2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ch = 8 * (li >> 2) + 4 * t + (li & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a1[t][j] = (__bf16)(g < 3 ? w[(g * 9 + j) * 32 + ch] : 0.0f);
+            a2[t][j] = (__bf16)((g < 3 && j == 0) ? w[(g * 9 + 8) * 32 + ch] : 0.0f);
+        }
+    }
+    float sc[8], sh[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        sc[r] = a.scale ? a.scale[8 * g + r] : 1.0f;
+        sh[r] = a.shift ? a.shift[8 * g + r] : 0.0f;
+    }
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    for (int chunk = wave_global; chunk < nchunk; chunk += nwaves) {
+        const int rowid = chunk / chunks_per_row;               // b * OH + oh
+        const int ow0 = (chunk - rowid * chunks_per_row) * 64;
+        const int b = rowid / a.OH, oh = rowid - b * a.OH;
+        const int ih = oh + g - 1;
+        const bool row_ok = g < 3 && (unsigned)ih < (unsigned)a.H;
+        // element offset of (b, ih, ow0 - 1, 0); the image is dense 3-channel fp32
+        const int rowoff = ((b * a.H + ih) * a.W + ow0 - 1) * 3;
+        bf16x8_first_t b1[4], b2[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int ow = ow0 + f * 16 + li;
+            const unsigned off = row_ok ? (unsigned)(rowoff + (f * 16 + li) * 3) * 4u : 0x80000000u;
+            // 12-byte pixels: offsets are only 4-byte aligned, so the run is read as three
+            // 12-byte loads (one per pixel), which need dword alignment only
+            typedef __attribute__((ext_vector_type(3))) unsigned int u3;
+            const u3 p0 = __builtin_amdgcn_raw_buffer_load_b96(xr, off, 0, 0);
+            const u3 p1 = __builtin_amdgcn_raw_buffer_load_b96(xr, off + 12u, 0, 0);
+            const u3 p2 = __builtin_amdgcn_raw_buffer_load_b96(xr, off + 24u, 0, 0);
+            f4 lo, hi;
+            lo[0] = __uint_as_float(p0[0]); lo[1] = __uint_as_float(p0[1]); lo[2] = __uint_as_float(p0[2]);
+            lo[3] = __uint_as_float(p1[0]); hi[0] = __uint_as_float(p1[1]); hi[1] = __uint_as_float(p1[2]);
+            hi[2] = __uint_as_float(p2[0]); hi[3] = __uint_as_float(p2[1]);
+            const float last = __uint_as_float(p2[2]);
+            const bool l_ok = ow >= 1, r_ok = ow + 1 < a.W;
+            b1[f][0] = (__bf16)(l_ok ? lo[0] : 0.0f);
+            b1[f][1] = (__bf16)(l_ok ? lo[1] : 0.0f);
+            b1[f][2] = (__bf16)(l_ok ? lo[2] : 0.0f);
+            b1[f][3] = (__bf16)lo[3];
+            b1[f][4] = (__bf16)hi[0];
+            b1[f][5] = (__bf16)hi[1];
+            b1[f][6] = (__bf16)(r_ok ? hi[2] : 0.0f);
+            b1[f][7] = (__bf16)(r_ok ? hi[3] : 0.0f);
+#pragma unroll
+            for (int j = 1; j < 8; ++j) b2[f][j] = (__bf16)0.0f;
+            b2[f][0] = (__bf16)(r_ok ? last : 0.0f);
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int ow = ow0 + f * 16 + li;
+            f32x4_first_t d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0], b1[f], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[1], b1[f], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0], b2[f], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1], b2[f], d1, 0, 0, 0);
+            if (ow < a.OW) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = act_f(d0[r] * sc[r] + sh[r], a.act);
+                    v[4 + r] = act_f(d1[r] * sc[4 + r] + sh[4 + r], a.act);
+                }
+                *(uint4 *)(y + ((size_t)rowid * a.OW + ow) * a.y_ld + 8 * g) =
+                    make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+            }
+        }
+    }
+}
+
+static bool first_layer_shape(const ConvArgs &a) {
+    return a.k == 3 && a.Cin == 3 && a.Cout == 32 && a.stride == 1 && a.dtype == YMX_BF16 &&
+           a.out_dtype == YMX_BF16 && a.res == nullptr && (a.y_ld & 7) == 0;
+}
+
 int launch_conv_direct(const ConvArgs &a, hipStream_t s) {
+    if (first_layer_shape(a) && a.x_dtype == YMX_F32 && a.x_ld == 3 && a.x_bytes != 0) {
+        const int cpr = (a.OW + 63) / 64;
+        const int nchunk = a.B * a.OH * cpr;
+        const int blocks = (nchunk + 3) / 4 < 256 * 8 ? (nchunk + 3) / 4 : 256 * 8;
+        hipLaunchKernelGGL((conv_first_rows_kernel<0>), dim3(blocks), dim3(256), 0, s, a, cpr, nchunk);
+        return check_launch("conv_first_rows");
+    }
+    if (first_layer_shape(a)) {
+        const int nchunk = (a.P + 63) / 64;
+        const int blocks = (nchunk + 3) / 4 < 256 * 8 ? (nchunk + 3) / 4 : 256 * 8;
+        if (a.x_dtype == YMX_F32)
+            hipLaunchKernelGGL((conv_first_mfma_kernel<float>), dim3(blocks), dim3(256), 0, s, a, nchunk);
+        else
+            hipLaunchKernelGGL((conv_first_mfma_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, a, nchunk);
+        return check_launch("conv_first_mfma");
+    }
     dim3 grid((a.P + 255) / 256, (a.Cout + 31) / 32), block(256);
     // the shortcut, when present, has the output's element type on this path
     if (a.x_dtype == YMX_F32 && a.out_dtype == YMX_F32)
