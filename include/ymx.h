@@ -44,8 +44,12 @@ const char *ymx_last_error(void);
 /* Process-wide tuning knobs (no counterpart in the reference).  "dma_min_tiles": the
  * fewest 256x256 output tiles for which a bf16 convolution with more than 128 output
  * channels runs on the large-tile LDS-DMA kernel instead of the 128x128 kernel
- * (default 160; 0 forces it, a huge value disables it).  Results do not depend on it
- * beyond fp32 summation order. */
+ * (default 160; 0 forces it, a huge value disables it).  "dma_variant": which large-tile
+ * kernel wide layers use (1: 256x256 tile, one workgroup per CU, the default; 2: 256x128
+ * tile, two per CU).  "dma_narrow": 1 (default) runs bf16 layers of <= 128 output
+ * channels with at least dma_min_tiles 256-pixel tiles on the LDS-DMA kernel, 0 on the
+ * register-staged kernel.  All kernels add the K terms in the same order: results do
+ * not depend on these options. */
 int ymx_set_option(const char *name, long long value);
 
 /* ---- convolution block ------------------------------------------------------

@@ -140,14 +140,23 @@ DMA_SHAPES = [
     (2, 26, 26, 768, 512, 1, False, "leaky", False),     # Cin not a power of two
     (1, 9, 11, 32, 384, 3, False, "mish", True),         # Cin 32 (two taps per K step), 1.5 tiles
     (1, 33, 31, 8, 200, 5, False, None, False),          # 5x5, Cin 8, several pixel tiles
+    # narrow layers: the several-workgroups-per-CU kernel with 128/64/32-channel tiles
+    (2, 24, 20, 64, 128, 3, False, "mish", True),
+    (1, 31, 33, 32, 64, 3, True, "mish", False),         # stride 2, one tap per K step
+    (2, 19, 17, 32, 64, 3, False, "mish", True),
+    (2, 21, 22, 64, 32, 1, False, "mish", False),        # 32-channel tile
+    (1, 15, 15, 128, 100, 1, False, "leaky", True),      # partial 128 tile
+    (1, 17, 9, 16, 24, 3, False, None, False),           # partial 32 tile, Cin 16
+    (1, 12, 12, 72, 48, 3, False, "mish", True),         # Cin not a power of two, partial 64 tile
 ]
 
 
 @pytest.mark.parametrize("case", range(len(DMA_SHAPES)))
 def test_conv_dma_kernel_forced(case):
-    """The 256-pixel x 256-channel LDS-DMA kernel on shapes it would not normally be
-    picked for (dma_min_tiles = 0), bf16 and fp32 outputs, against the oracle and against
-    the 128x128 kernel (same summation order: identical bits)."""
+    """The LDS-DMA kernels (both wide-layer variants and the narrow-layer tiles) on shapes
+    they would not normally be picked for (dma_min_tiles = 0), bf16 and fp32 outputs,
+    against the oracle and against the register-staged kernel (same summation order:
+    identical bits)."""
     from yolo_amd import _lib
     B, H, W, cin, cout, k, down, act, use_res = DMA_SHAPES[case]
     g = torch.Generator().manual_seed(300 + case)
@@ -167,13 +176,17 @@ def test_conv_dma_kernel_forced(case):
         _lib.check(L.ymx_set_option(b"dma_min_tiles", 1 << 40))
         y_small = layer(xin, residual=rin)
         _lib.check(L.ymx_set_option(b"dma_min_tiles", 0))
-        y = layer(xin, residual=rin)
-        y32 = layer(xin, residual=rin, out_dtype=torch.float32)
+        _lib.check(L.ymx_set_option(b"dma_narrow", 1))
+        for variant in (1, 2):       # 256x256 tile / 1 workgroup per CU, 256x128 tile / 2 per CU
+            _lib.check(L.ymx_set_option(b"dma_variant", variant))
+            y = layer(xin, residual=rin)
+            y32 = layer(xin, residual=rin, out_dtype=torch.float32)
+            assert rel_err(y.float().cpu().numpy(), want.numpy()) < 1e-2, variant
+            assert rel_err(y32.cpu().numpy(), want.numpy()) < 1e-3, variant
+            assert torch.equal(y, y_small), variant
     finally:
         _lib.check(L.ymx_set_option(b"dma_min_tiles", 160))
-    assert rel_err(y.float().cpu().numpy(), want.numpy()) < 1e-2
-    assert rel_err(y32.cpu().numpy(), want.numpy()) < 1e-3
-    assert torch.equal(y, y_small)
+        _lib.check(L.ymx_set_option(b"dma_variant", 1))
 
 
 def test_layers_standalone():

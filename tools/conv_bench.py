@@ -20,6 +20,7 @@ DEFAULT = [
     (64, 52, 52, 256, 128, 1, 1), (64, 26, 26, 256, 512, 3, 1), (64, 26, 26, 512, 256, 1, 1),
     (64, 13, 13, 512, 1024, 3, 1), (64, 13, 13, 1024, 512, 1, 1), (64, 104, 104, 64, 128, 3, 1),
     (64, 208, 208, 32, 64, 3, 1), (64, 416, 416, 32, 64, 3, 2), (64, 208, 208, 64, 32, 1, 1),
+    (64, 208, 208, 64, 128, 3, 2), (64, 104, 104, 128, 64, 1, 1),
 ]
 
 
@@ -46,10 +47,14 @@ def main():
         res = torch.randn(B, oh, ow, cout, generator=g).cuda().bfloat16()
         flops = 2.0 * B * oh * ow * k * k * cin * cout
         line = "B%d %dx%d %4d->%4d k%d s%d :" % (B, H, W, cin, cout, k, stride)
-        for kern, tiles in (("128", 1 << 40), ("dma", 0)):
-            if kern == "dma" and cout <= 128:
+        for kern, tiles, variant in (("128", 1 << 40, 1), ("dma1", 0, 1), ("dma2", 0, 2)):
+            if kern == "dma1" and cout <= 128:
+                continue
+            if kern == "128" and os.environ.get("SKIP128"):
                 continue
             _lib.check(L.ymx_set_option(b"dma_min_tiles", tiles))
+            _lib.check(L.ymx_set_option(b"dma_variant", variant))
+            _lib.check(L.ymx_set_option(b"dma_narrow", 0 if kern == "128" else 1))
             for act, use_res in ((None, False), ("mish", False), ("mish", True)):
                 layer = YOLOConv((k, k, cout), downsample=(stride == 2), activation=act, dtype=torch.bfloat16)
                 layer.build(cin, generator=g)

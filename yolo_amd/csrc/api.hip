@@ -35,6 +35,8 @@ static bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 // Fewest 256x256 tiles for which the large-tile kernel is chosen (one workgroup per CU,
 // 256 CUs).  YMX_DMA_MIN_TILES overrides it for experiments (a huge value disables the
 // kernel, 0 forces it).
+static long long g_dma_variant = 1;      // wide layers: 1 = 256x256 tile, 1 workgroup/CU; 2 = 256x128 tile, 2 workgroups/CU
+static long long g_dma_narrow = 1;       // layers of <= 128 output channels: 1 = LDS-DMA kernel, 0 = register-staged kernel
 static long long g_dma_min_tiles = -1;
 static long long dma_min_tiles() {
     if (g_dma_min_tiles < 0) {
@@ -94,8 +96,12 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         // and has enough of them to occupy the chip; the 128x128 kernel otherwise.
         if (dtype == YMX_BF16 && Cout > 128) {
             const long long tiles = ((long long)(a.P + 255) / 256) * ((Cout + 255) / 256);
-            if (tiles >= dma_min_tiles()) return launch_conv_igemm_dma(a, s);
+            if (tiles >= dma_min_tiles()) return g_dma_variant == 1 ? launch_conv_igemm_dma(a, s) : launch_conv_igemm_dma2(a, s);
         }
+        // Narrow layers (the first backbone stages): memory-bound; the several-workgroups-
+        // per-CU LDS-DMA kernel with channel tiles of 32/64/128.
+        if (dtype == YMX_BF16 && Cout <= 128 && g_dma_narrow && (a.P + 255) / 256 >= dma_min_tiles())
+            return launch_conv_igemm_dma2(a, s);
         return launch_conv_igemm(a, s);
     }
     if (!aligned16(y)) return fail(YMX_EARG, "conv2d: y must be 16-byte aligned");
@@ -122,6 +128,16 @@ int ymx_set_option(const char *name, long long value) {
     if (!strcmp(name, "dma_min_tiles")) {
         if (value < 0) return fail(YMX_EARG, "set_option: dma_min_tiles must be >= 0");
         g_dma_min_tiles = value;
+        return YMX_OK;
+    }
+    if (!strcmp(name, "dma_variant")) {
+        if (value != 1 && value != 2) return fail(YMX_EARG, "set_option: dma_variant must be 1 or 2");
+        g_dma_variant = value;
+        return YMX_OK;
+    }
+    if (!strcmp(name, "dma_narrow")) {
+        if (value != 0 && value != 1) return fail(YMX_EARG, "set_option: dma_narrow must be 0 or 1");
+        g_dma_narrow = value;
         return YMX_OK;
     }
     return fail(YMX_EARG, "set_option: unknown option '%s'", name);

@@ -87,6 +87,7 @@ static inline int packed_rows(int Cout) { return ((Cout + 127) / 128) * 128; }
 
 int launch_conv_igemm(const ConvArgs &a, hipStream_t s);
 int launch_conv_igemm_dma(const ConvArgs &a, hipStream_t s);
+int launch_conv_igemm_dma2(const ConvArgs &a, hipStream_t s);
 int launch_conv_direct(const ConvArgs &a, hipStream_t s);
 int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype,
                         hipStream_t s);

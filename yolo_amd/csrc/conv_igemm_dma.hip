@@ -16,41 +16,9 @@
 //    hardware writes zeros into LDS: padding costs no branch and no memory traffic;
 //  - two LDS stages of (256 + TQ) x 128 B; the DMA of tile t+1 is issued before the
 //    MFMAs of tile t and waited for (vmcnt(0)) after them, one barrier per K step.
-#include "common.h"
+#include "lds_dma.h"
 
 namespace ymx {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef __attribute__((ext_vector_type(4))) int i32x4_t;
-
-// 128-bit raw buffer descriptor (base, stride 0, byte extent) held in SGPRs.
-__device__ __forceinline__ i32x4_t make_rsrc(const void *p, unsigned bytes) {
-    const unsigned long long addr = (unsigned long long)p;
-    i32x4_t r;
-    r[0] = __builtin_amdgcn_readfirstlane((int)(addr & 0xffffffffull));
-    r[1] = __builtin_amdgcn_readfirstlane((int)((addr >> 32) & 0xffffull));
-    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
-    r[3] = __builtin_amdgcn_readfirstlane(0x00020000);
-    return r;
-}
-
-// One LDS-DMA wave-instruction: lane l's 16 bytes at buffer offset `voff` land at LDS byte
-// address lds_addr + 16*l (zeros if voff is out of range).  Written as inline asm on
-// purpose: the compiler neither counts it in vmcnt nor orders LDS reads behind it, so
-// the transfer overlaps the MFMAs that follow; the caller waits (vmcnt) and then
-// barriers before any wave reads the bytes.  M0 carries the LDS base and is restored.
-__device__ __forceinline__ void lds_dma16(const i32x4_t rsrc, unsigned lds_addr, unsigned voff) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %2\n\t"
-                 "s_nop 4\n\t"
-                 "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(lds_addr), "s"(rsrc)
-                 : "memory");
-}
 
 template <typename OT, int TQ>
 __global__ void __launch_bounds__(512, 2)
