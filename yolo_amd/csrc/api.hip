@@ -79,6 +79,8 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         return fail(YMX_EUNSUPPORTED, "conv2d: tensor exceeds 2^31 elements");
     a.P = (int)P;
     a.K = k * k * Cin;
+    set_fastdiv((unsigned)(a.OH * a.OW), a.ohw_m, a.ohw_s);
+    set_fastdiv((unsigned)a.OW, a.ow_m, a.ow_s);
     a.act = act;
     a.dtype = dtype; a.x_dtype = x_dtype; a.out_dtype = out_dtype;
     if (conv_uses_mfma(Cin, dtype)) {
@@ -92,6 +94,10 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         if (xb > 0x80000000LL) return fail(YMX_EUNSUPPORTED, "conv2d: input larger than 2 GiB (%lld bytes)", xb);
         a.x_bytes = (unsigned)xb;
         a.w_bytes = (unsigned)((size_t)packed_rows(Cout) * a.Kw * (dtype == YMX_BF16 ? 2 : 4));
+        if (residual) {
+            const long long rb = ((P - 1) * a.res_ld + Cout) * (dtype == YMX_BF16 ? 2 : 4);
+            a.res_bytes = rb < 0x80000000LL ? (unsigned)rb : 0u;
+        }
         // Large-tile LDS-DMA kernel when the layer is wide enough to fill 256-channel tiles
         // and has enough of them to occupy the chip; the 128x128 kernel otherwise.
         if (dtype == YMX_BF16 && Cout > 128) {
@@ -133,6 +139,11 @@ int ymx_set_option(const char *name, long long value) {
     if (!strcmp(name, "dma_variant")) {
         if (value != 1 && value != 2) return fail(YMX_EARG, "set_option: dma_variant must be 1 or 2");
         g_dma_variant = value;
+        return YMX_OK;
+    }
+    if (!strcmp(name, "dma_stages")) {
+        if (value != 3 && value != 4) return fail(YMX_EARG, "set_option: dma_stages must be 3 or 4");
+        g_dma2_stages = (int)value;
         return YMX_OK;
     }
     if (!strcmp(name, "dma_narrow")) {

@@ -49,14 +49,27 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // v_exp_f32 and v_rcp_f32 are 1-ulp instructions; the clamp keeps n finite (for
 // x >= 20 the ratio is 1 to fp32 precision, so the result is x), and the product form
 // keeps full relative accuracy for very negative x, where the result is ~ x*e^x.
+//
+// Floating-point contraction is switched off inside these helpers and the affine step is an
+// explicit fma: every convolution kernel, whatever its tiling and however the compiler
+// sees the surrounding code, must produce the same bits for the same accumulator.
+__device__ __forceinline__ float affine_f(float v, float sc, float sh) { return __builtin_fmaf(v, sc, sh); }
 __device__ __forceinline__ float mish_f(float x) {
+#pragma clang fp contract(off)
     const float e = __builtin_amdgcn_exp2f(fminf(x, 20.0f) * 1.44269504088896f);
     const float n = e * (e + 2.0f);
     return x * (n * __builtin_amdgcn_rcpf(n + 2.0f));
 }
 __device__ __forceinline__ float act_f(float v, int act) {
+#pragma clang fp contract(off)
     if (act == YMX_ACT_MISH) return mish_f(v);
     if (act == YMX_ACT_LEAKY) return v > 0.0f ? v : 0.1f * v;
+    return v;
+}
+template <int ACT> __device__ __forceinline__ float act_c(float v) {
+#pragma clang fp contract(off)
+    if constexpr (ACT == YMX_ACT_MISH) return mish_f(v);
+    if constexpr (ACT == YMX_ACT_LEAKY) return v > 0.0f ? v : 0.1f * v;
     return v;
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -76,7 +89,42 @@ struct ConvArgs {
     int dtype, x_dtype, out_dtype;
     unsigned x_bytes;            // extent of x in bytes (buffer-load bounds), <= 2^31
     unsigned w_bytes;            // extent of the packed weights in bytes
+    unsigned res_bytes;          // extent of the shortcut input in bytes (0: none, or beyond 4 GiB)
+    unsigned ohw_m, ohw_s;       // p / (OH*OW) and p / OW for 0 <= p < 2^31 without a division:
+    unsigned ow_m, ow_s;         //   m == 0 ? p : __umulhi(p, m) >> s   (set_fastdiv below)
 };
+
+// Multiply-shift division of a 31-bit dividend by d >= 1: with l = ceil(log2 d) and
+// m = ceil(2^(31+l) / d) (< 2^32), floor(n / d) = (n * m) >> (31 + l) for all n < 2^31,
+// because the excess n * (m*d - 2^(31+l)) / (d * 2^(31+l)) stays below 1/d.  d = 1 is
+// flagged by m = 0.
+static inline void set_fastdiv(unsigned d, unsigned &m, unsigned &s) {
+    if (d <= 1) { m = 0; s = 0; return; }
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    m = (unsigned)(((1ull << (31 + l)) + d - 1) / d);
+    s = l - 1;
+}
+__device__ __forceinline__ int fastdiv(int n, unsigned m, unsigned s) {
+    return m == 0 ? n : (int)(__umulhi((unsigned)n, m) >> s);
+}
+
+// Where output pixel p reads its input: element offset of (b, ih0, iw0, channel 0) -- it may
+// be negative -- and the bit mask (bit r*k+c) of the taps that fall inside the image.
+__device__ __forceinline__ void pixel_geometry(const ConvArgs &a, int p, int &off, unsigned &mask) {
+    off = 0;
+    mask = 0;
+    if (p < a.P) {
+        const int b = fastdiv(p, a.ohw_m, a.ohw_s), rem = p - b * (a.OH * a.OW);
+        const int oh = fastdiv(rem, a.ow_m, a.ow_s), ow = rem - oh * a.OW;
+        const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
+        off = ((b * a.H + ih0) * a.W + iw0) * a.x_ld;
+        const int clo = max(0, -iw0), chi = max(0, min(a.k, a.W - iw0));
+        const unsigned cols = ((1u << chi) - 1u) & ~((1u << clo) - 1u);
+        for (int r = 0; r < a.k; ++r)
+            mask |= ((unsigned)(ih0 + r) < (unsigned)a.H ? cols : 0u) << (r * a.k);
+    }
+}
 
 // Packed weight geometry, shared by pack and conv.
 static inline bool conv_uses_mfma(int Cin, int dtype) {
@@ -88,6 +136,7 @@ static inline int packed_rows(int Cout) { return ((Cout + 127) / 128) * 128; }
 int launch_conv_igemm(const ConvArgs &a, hipStream_t s);
 int launch_conv_igemm_dma(const ConvArgs &a, hipStream_t s);
 int launch_conv_igemm_dma2(const ConvArgs &a, hipStream_t s);
+extern int g_dma2_stages;
 int launch_conv_direct(const ConvArgs &a, hipStream_t s);
 int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype,
                         hipStream_t s);

@@ -58,7 +58,7 @@ conv_direct_kernel(const ConvArgs a) {
         const int cc = min(q0 + co, a.Cout - 1);
         const float sc = a.scale ? a.scale[cc] : 1.0f;
         const float sh = a.shift ? a.shift[cc] : 0.0f;
-        v[co] = act_f(acc[co] * sc + sh, a.act);
+        v[co] = act_f(affine_f(acc[co], sc, sh), a.act);
         if (res) v[co] += elem<OT>::load(res + cc);
     }
     const bool full = q0 + CO <= a.Cout;
@@ -156,8 +156,8 @@ conv_first_mfma_kernel(const ConvArgs a, const int nchunk) {
                 float v[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = act_f(d0[r] * sc[r] + sh[r], a.act);
-                    v[4 + r] = act_f(d1[r] * sc[4 + r] + sh[4 + r], a.act);
+                    v[r] = act_f(affine_f(d0[r], sc[r], sh[r]), a.act);
+                    v[4 + r] = act_f(affine_f(d1[r], sc[4 + r], sh[4 + r]), a.act);
                 }
                 *(uint4 *)(y + (size_t)pix[f] * a.y_ld + 8 * g) =
                     make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
@@ -249,8 +249,8 @@ conv_first_rows_kernel(const ConvArgs a, const int chunks_per_row, const int nch
                 float v[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = act_f(d0[r] * sc[r] + sh[r], a.act);
-                    v[4 + r] = act_f(d1[r] * sc[4 + r] + sh[4 + r], a.act);
+                    v[r] = act_f(affine_f(d0[r], sc[r], sh[r]), a.act);
+                    v[4 + r] = act_f(affine_f(d1[r], sc[4 + r], sh[4 + r]), a.act);
                 }
                 *(uint4 *)(y + ((size_t)rowid * a.OW + ow) * a.y_ld + 8 * g) =
                     make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));

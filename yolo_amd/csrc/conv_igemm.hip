@@ -217,7 +217,7 @@ conv_igemm_kernel(const ConvArgs a, const int ntile_q, const int nk) {
             if (p >= a.P || co >= a.Cout) continue;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_f(acc[i][j][r] * sc[r] + sh[r], a.act);
+            for (int r = 0; r < 4; ++r) v[r] = act_f(affine_f(acc[i][j][r], sc[r], sh[r]), a.act);
             if (vec_ok) {
                 if (res) {
                     const T *rp = res + (size_t)p * a.res_ld + co;

@@ -206,10 +206,10 @@ conv_igemm_dma_kernel(const ConvArgs a, const int ntile_q, const int nk) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 float4 v;
-                v.x = act_f(acc[i][j][0] * sc[0] + sh[0], act);
-                v.y = act_f(acc[i][j][1] * sc[1] + sh[1], act);
-                v.z = act_f(acc[i][j][2] * sc[2] + sh[2], act);
-                v.w = act_f(acc[i][j][3] * sc[3] + sh[3], act);
+                v.x = act_f(affine_f(acc[i][j][0], sc[0], sh[0]), act);
+                v.y = act_f(affine_f(acc[i][j][1], sc[1], sh[1]), act);
+                v.z = act_f(affine_f(acc[i][j][2], sc[2], sh[2]), act);
+                v.w = act_f(affine_f(acc[i][j][3], sc[3], sh[3]), act);
                 const int px = j * 16 + (lane & 15);
                 *(float4 *)(tbase + px * 256 + ((slot ^ (px & 15)) << 4)) = v;
             }

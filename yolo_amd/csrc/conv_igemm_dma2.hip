@@ -12,29 +12,28 @@
 //                  TQ <= 128: 1 x 4 waves of TQ ch x 64 px, TP = 256
 //   K step         32 (one mfma_f32_16x16x32_bf16 deep): LDS rows of 64 B; a 3x3 conv
 //                  with 32 input channels is exactly one tap per step
-//   LDS            3 stages x (TP + max(TQ, 64)) rows x 64 B  (60 .. 72 KB)
-//   pipeline       step s: issue DMA of tile s+2, MFMAs of tile s, wait for tile s+1
-//                  (counted vmcnt: the pieces just issued may stay in flight), one
-//                  barrier.  A tile therefore has two full steps to land.
+//   LDS            NSTAGE (3 or 4) stages x (TP + max(TQ, 64)) rows x 64 B  (72 .. 80 KB)
+//   pipeline       step s: issue DMA of tile s+NSTAGE-1, MFMAs of tile s, wait for tile
+//                  s+1 (counted vmcnt: the younger pieces may stay in flight), one
+//                  barrier.  A tile therefore has NSTAGE-1 full steps to land.
+//   shortcut       the residual input is fetched into registers before the K loop
 //   epilogue       per-wave transpose through LDS (fp32, XOR-swizzled), bias/BN,
-//                  activation, shortcut, one rounding, 128 (or 64) contiguous bytes per
-//                  pixel per store instruction
+//                  activation, shortcut, one rounding, 16-byte stores, 128 (or 64)
+//                  contiguous bytes per pixel per store instruction
 //
 // LDS image of one DMA piece (one wave-instruction, 1 KB) = 16 rows x 64 B.  The 16-byte
 // slot of K-chunk c in row r is  c ^ ((-(r >> 2)) & 3): with that XOR the ds_read_b128
 // fragment reads (16 rows x one chunk per 16-lane group) touch 16 distinct slots of the
 // 256-byte bank row.  The swizzle is applied to the DMA's source address (the lane filling
 // slot s of row r fetches chunk s ^ f(r)), the LDS image itself stays linear.
+#include <type_traits>
 #include "lds_dma.h"
 
 namespace ymx {
 
-template <int N> struct vmcnt_wait;
-template <> struct vmcnt_wait<5> { __device__ static __forceinline__ void run() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); } };
-template <> struct vmcnt_wait<6> { __device__ static __forceinline__ void run() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } };
-template <> struct vmcnt_wait<8> { __device__ static __forceinline__ void run() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } };
+template <int N> __device__ __forceinline__ void vmcnt_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename OT, int TQ>
+template <typename OT, int TQ, int NSTAGE>
 __global__ void __launch_bounds__(256, 2)
 conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     constexpr int WGQ = TQ >= 256 ? 2 : 1, WGP = 4 / WGQ;       // wave grid: channels x pixels
@@ -43,14 +42,18 @@ conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     constexpr int WROWS = TQ < 64 ? 64 : TQ;                     // weight rows staged (zero rows beyond Cout)
     constexpr int NXI = TP / 64, NWI = WROWS / 64;               // DMA pieces per wave per step
     constexpr int NPIECE = NXI + NWI;
-    constexpr int XBYTES = TP * 64, STAGE = (TP + WROWS) * 64, NSTAGE = 3;
+    constexpr int XBYTES = TP * 64, STAGE = (TP + WROWS) * 64;
+    constexpr int INFLIGHT = NPIECE * (NSTAGE - 2);             // pieces that may still be in flight at a step's end
     constexpr int HQ = WQ < 64 ? WQ : 64, NH = WQ / HQ;          // epilogue: channel halves of <= 64
-    constexpr int SLOTS = HQ / 4, PPI = 64 / SLOTS;              // 16-byte slots per row, pixels per instruction
+    constexpr int SLOTS = HQ / 4, LPP = SLOTS / 2;               // 16-byte slots per fp32 row; lanes per pixel (8 channels each)
+    constexpr int PPI = 64 / LPP, NPASS = WP / PPI;              // pixels per store instruction; instructions per half
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
     constexpr unsigned OOB = 0x80000000u;
     // (the launcher sizes the dynamic LDS as max(pipeline stages, 4 per-wave transpose images))
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    YMX_STAMP(0);
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wq = wave % WGQ, wp = wave / WGQ;
@@ -66,29 +69,8 @@ conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     const int chunk = (lane & 3) ^ ((-(srow >> 2)) & 3);        // K-chunk (8 elements) fetched
     int xoff[NXI];
     unsigned xmask[NXI];
-    {
-        const int ohw = a.OH * a.OW;
 #pragma unroll
-        for (int i = 0; i < NXI; ++i) {
-            const int p = p0 + (wave * NXI + i) * 16 + srow;
-            int off = 0;
-            unsigned m = 0;
-            if (p < a.P) {
-                const int b = p / ohw, rem = p - b * ohw;
-                const int oh = rem / a.OW, ow = rem - oh * a.OW;
-                const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
-                off = ((b * a.H + ih0) * a.W + iw0) * a.x_ld;
-                for (int r = 0; r < a.k; ++r)
-                    for (int c = 0; c < a.k; ++c) {
-                        const bool ok = (unsigned)(ih0 + r) < (unsigned)a.H &&
-                                        (unsigned)(iw0 + c) < (unsigned)a.W;
-                        m |= (ok ? 1u : 0u) << (r * a.k + c);
-                    }
-            }
-            xoff[i] = off;
-            xmask[i] = m;
-        }
-    }
+    for (int i = 0; i < NXI; ++i) pixel_geometry(a, p0 + (wave * NXI + i) * 16 + srow, xoff[i], xmask[i]);
     int ci = chunk * 8, tap = 0, tr = 0, tc = 0;
     while (ci >= a.Cin) {
         ci -= a.Cin;
@@ -123,6 +105,34 @@ conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
         }
     };
 
+    // ---- shortcut input: fetched now, in the store pattern of the epilogue, so that its
+    // latency is hidden behind the whole K loop (it is older than every DMA piece, so the
+    // counted waits below cover it as well)
+    const bf16_t *__restrict__ res = (const bf16_t *)a.res;
+    const bool vec_ok = ((a.Cout & 7) == 0) && ((a.y_ld & 7) == 0) && (res == nullptr || (a.res_ld & 7) == 0);
+    const bool res_pre = res != nullptr && vec_ok && a.res_bytes != 0;
+    const int sl = lane % LPP;                                   // epilogue: this lane's 8-channel group
+    const __amdgpu_buffer_rsrc_t rrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)a.res, 0, res_pre ? (int)a.res_bytes : 0, 0x00020000);
+    auto load_res = [&](int half, u32x4_t (&r)[NPASS]) {
+        const int co = q0 + wq * WQ + half * HQ + sl * 8;
+#pragma unroll
+        for (int n = 0; n < NPASS; ++n) {
+            const int p = p0 + wp * WP + n * PPI + lane / LPP;
+            const unsigned off = (p < a.P && co < a.Cout) ? ((unsigned)p * (unsigned)a.res_ld + (unsigned)co) * 2u : OOB;
+            r[n] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
+        }
+    };
+    // 64-channel wave tiles fetch it here; 128-channel ones (short of registers) fetch the
+    // first half before the last K step and the second half during the epilogue
+    u32x4_t rpre[NH][NPASS];
+    if (res_pre && NH == 1) {
+        load_res(0, rpre[0]);
+    } else {
+#pragma unroll
+        for (int n = 0; n < NPASS; ++n) rpre[0][n] = u32x4_t{0u, 0u, 0u, 0u};
+    }
+
     f32x4_t acc[NI][NJ];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -151,84 +161,146 @@ conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
         }
     };
 
-    dma(0, 0);
-    dma(1, 1);
-    vmcnt_wait<NPIECE>::run();
+    YMX_STAMP(1);
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; ++i) dma(i, i);
+    vmcnt_wait<INFLIGHT>();
     __syncthreads();
+    YMX_STAMP(2);
     int st = 0;                                          // stage of tile s
-    for (int s = 0; s < nk; ++s) {
-        int st2 = st + 2;
-        if (st2 >= NSTAGE) st2 -= NSTAGE;
-        dma(s + 2, st2);
+    auto step = [&](int s) {
+        int stn = st + NSTAGE - 1;
+        if (stn >= NSTAGE) stn -= NSTAGE;
+        dma(s + NSTAGE - 1, stn);
         compute(st);
-        vmcnt_wait<NPIECE>::run();
+        vmcnt_wait<INFLIGHT>();
         __syncthreads();
         st = st + 1 == NSTAGE ? 0 : st + 1;
+    };
+    for (int s = 0; s < nk - 1; ++s) step(s);
+    if constexpr (NH == 2) {
+        if (res_pre) load_res(0, rpre[0]);               // older than the last step's pieces: the counted wait holds
     }
+    step(nk - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    YMX_STAMP(3);
 
     // ---- epilogue: per-wave transpose through LDS ------------------------------------
+    // The raw accumulators go to LDS as fp32 rows [pixel][HQ channels] (16-byte slots
+    // XOR-swizzled by pixel); each lane then reads back 8 consecutive channels of one
+    // pixel, applies scale/shift, activation and shortcut, rounds once and stores 16
+    // bytes (bf16) -- a pixel's channels are one contiguous run per store instruction.
+    // The common case (16-byte aligned rows, shortcut prefetched or absent) is compiled
+    // once per activation so that the per-value code is branch-free.
     OT *__restrict__ y = (OT *)a.y;
-    const bf16_t *__restrict__ res = (const bf16_t *)a.res;
-    const bool vec_ok = ((a.Cout & 3) == 0) && ((a.y_ld & 3) == 0) && (res == nullptr || (a.res_ld & 3) == 0);
     char *tbase = smem + wave * (WP * HQ * 4);
-    const int act = a.act;
-#pragma unroll
-    for (int half = 0; half < NH; ++half) {
+    auto to_lds = [&](int half) {
 #pragma unroll
         for (int il = 0; il < HQ / 16; ++il) {
-            const int i = half * (HQ / 16) + il;
-            const int co = q0 + wq * WQ + i * 16 + 4 * (lane >> 4);
-            float sc[4], sh[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = co + r;
-                const bool in = c < a.Cout;
-                sc[r] = in ? (a.scale ? a.scale[c] : 1.0f) : 0.0f;
-                sh[r] = (in && a.shift) ? a.shift[c] : 0.0f;
-            }
             const int slot = il * 4 + (lane >> 4);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                float4 v;
-                v.x = act_f(acc[i][j][0] * sc[0] + sh[0], act);
-                v.y = act_f(acc[i][j][1] * sc[1] + sh[1], act);
-                v.z = act_f(acc[i][j][2] * sc[2] + sh[2], act);
-                v.w = act_f(acc[i][j][3] * sc[3] + sh[3], act);
                 const int px = j * 16 + (lane & 15);
-                *(float4 *)(tbase + px * (HQ * 4) + ((slot ^ (px & (SLOTS - 1))) << 4)) = v;
+                *(f32x4_t *)(tbase + px * (HQ * 4) + ((slot ^ (px & (SLOTS - 1))) << 4)) = acc[half * (HQ / 16) + il][j];
             }
         }
-        // rows back out: lane -> pixel PPI*n + lane / SLOTS, channels 4*(lane % SLOTS) .. +3
-        const int slot = lane % SLOTS;
-        const int co = q0 + wq * WQ + half * HQ + slot * 4;
-#pragma unroll 4
-        for (int n = 0; n < WP / PPI; ++n) {
-            const int px = n * PPI + lane / SLOTS;
-            const int p = p0 + wp * WP + px;
-            float4 v = *(const float4 *)(tbase + px * (HQ * 4) + ((slot ^ (px & (SLOTS - 1))) << 4));
-            if (p >= a.P || co >= a.Cout) continue;
-            if (vec_ok) {
-                if (res) {
-                    const uint2 rv = *(const uint2 *)(res + (size_t)p * a.res_ld + co);
-                    v.x += __uint_as_float(rv.x << 16);
-                    v.y += __uint_as_float(rv.x & 0xffff0000u);
-                    v.z += __uint_as_float(rv.y << 16);
-                    v.w += __uint_as_float(rv.y & 0xffff0000u);
-                }
-                OT *yp = y + (size_t)p * a.y_ld + co;
-                if constexpr (sizeof(OT) == 2) {
-                    *(uint2 *)yp = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
-                } else {
-                    *(float4 *)yp = v;
-                }
-            } else {
-                const float vv[4] = {v.x, v.y, v.z, v.w};
+    };
+    auto read_row = [&](int px, float (&v)[8]) {
+        const char *row = tbase + px * (HQ * 4);
+        const int sw = px & (SLOTS - 1);
+        const float4 v0 = *(const float4 *)(row + (((2 * sl) ^ sw) << 4));
+        const float4 v1 = *(const float4 *)(row + (((2 * sl + 1) ^ sw) << 4));
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+        v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+    };
+    auto load_affine = [&](int half, float (&sc)[8], float (&sh)[8]) {
+        const int co = q0 + wq * WQ + half * HQ + sl * 8;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 8; ++r) {
+            const int c = co + r;
+            const bool in = c < a.Cout;
+            sc[r] = in ? (a.scale ? a.scale[c] : 1.0f) : 0.0f;
+            sh[r] = (in && a.shift) ? a.shift[c] : 0.0f;
+        }
+    };
+
+    auto fast = [&](auto act_tag, auto res_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        constexpr bool RES = decltype(res_tag)::value;
+#pragma unroll
+        for (int half = 0; half < NH; ++half) {
+            float sc[8], sh[8];
+            if constexpr (RES && NH == 2) {
+                if (half == 1) load_res(1, rpre[NH - 1]);      // lands while the accumulators go to LDS
+            }
+            load_affine(half, sc, sh);
+            to_lds(half);
+            if (half == 0) YMX_STAMP(4);
+            const int co = q0 + wq * WQ + half * HQ + sl * 8;
+            float nxt[8];
+            read_row(lane / LPP, nxt);
+#pragma unroll
+            for (int n = 0; n < NPASS; ++n) {
+                const int px = n * PPI + lane / LPP;
+                const int p = p0 + wp * WP + px;
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = nxt[r];
+                if (n + 1 < NPASS) read_row(px + PPI, nxt);     // next pass's row is in flight during this one's math
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = act_c<ACT>(affine_f(v[r], sc[r], sh[r]));
+                if constexpr (RES) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // a separately rounded add (no fusing with the activation's last
+                        // multiply): every conv kernel must give the same bits
+                        v[2 * r] = __fadd_rn(v[2 * r], __uint_as_float(rpre[half][n][r] << 16));
+                        v[2 * r + 1] = __fadd_rn(v[2 * r + 1], __uint_as_float(rpre[half][n][r] & 0xffff0000u));
+                    }
+                }
+                if (p < a.P && co < a.Cout) {
+                    OT *yp = y + (size_t)p * a.y_ld + co;
+                    if constexpr (sizeof(OT) == 2) {
+                        *(uint4 *)yp = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]),
+                                                  pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+                    } else {
+                        *(float4 *)yp = make_float4(v[0], v[1], v[2], v[3]);
+                        *(float4 *)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto fast_act = [&](auto res_tag) {
+        if (a.act == YMX_ACT_MISH) fast(std::integral_constant<int, YMX_ACT_MISH>{}, res_tag);
+        else if (a.act == YMX_ACT_LEAKY) fast(std::integral_constant<int, YMX_ACT_LEAKY>{}, res_tag);
+        else fast(std::integral_constant<int, YMX_ACT_NONE>{}, res_tag);
+    };
+
+    if (vec_ok && res == nullptr) {
+        fast_act(std::false_type{});
+    } else if (res_pre) {
+        fast_act(std::true_type{});
+    } else {
+        // odd channel counts or pixel strides (e.g. the 255-channel output layers)
+        const int act = a.act;
+        for (int half = 0; half < NH; ++half) {
+            float sc[8], sh[8];
+            load_affine(half, sc, sh);
+            to_lds(half);
+            const int co = q0 + wq * WQ + half * HQ + sl * 8;
+            for (int n = 0; n < NPASS; ++n) {
+                const int px = n * PPI + lane / LPP;
+                const int p = p0 + wp * WP + px;
+                float v[8];
+                read_row(px, v);
+                if (p >= a.P) continue;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
                     if (co + r < a.Cout) {
-                        float o = vv[r];
+                        float o = act_f(affine_f(v[r], sc[r], sh[r]), act);
                         if (res) o += bf16_to_f32(res[(size_t)p * a.res_ld + co + r]);
                         elem<OT>::store(y + (size_t)p * a.y_ld + co + r, o);
                     }
@@ -236,16 +308,17 @@ conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
             }
         }
     }
+    YMX_STAMP_END(5);
 }
 
-template <typename OT, int TQ>
+template <typename OT, int TQ, int NSTAGE>
 static int launch_dma2_cfg(const ConvArgs &a, hipStream_t s) {
     constexpr int TP = TQ >= 256 ? 128 : 256;
     constexpr int WROWS = TQ < 64 ? 64 : TQ;
     constexpr int HQ = (TQ >= 256 ? 128 : TQ) < 64 ? TQ : 64;
-    constexpr int PIPE = 3 * (TP + WROWS) * 64, EPI = 4 * 64 * HQ * 4;
+    constexpr int PIPE = NSTAGE * (TP + WROWS) * 64, EPI = 4 * 64 * HQ * 4;
     constexpr int LDS = PIPE > EPI ? PIPE : EPI;
-    auto kern = conv_igemm_dma2_kernel<OT, TQ>;
+    auto kern = conv_igemm_dma2_kernel<OT, TQ, NSTAGE>;
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -263,12 +336,18 @@ static int launch_dma2_cfg(const ConvArgs &a, hipStream_t s) {
     return check_launch("conv_igemm_dma2");
 }
 
+int g_dma2_stages = 4;    // pipeline depth of the 32- and 64-channel tiles (3 or 4)
+
 template <typename OT>
 static int launch_dma2_shape(const ConvArgs &a, hipStream_t s) {
-    if (a.Cout <= 32) return launch_dma2_cfg<OT, 32>(a, s);
-    if (a.Cout <= 64) return launch_dma2_cfg<OT, 64>(a, s);
-    if (a.Cout <= 128) return launch_dma2_cfg<OT, 128>(a, s);
-    return launch_dma2_cfg<OT, 256>(a, s);
+    if (g_dma2_stages == 4) {
+        if (a.Cout <= 32) return launch_dma2_cfg<OT, 32, 4>(a, s);
+        if (a.Cout <= 64) return launch_dma2_cfg<OT, 64, 4>(a, s);
+    }
+    if (a.Cout <= 32) return launch_dma2_cfg<OT, 32, 3>(a, s);
+    if (a.Cout <= 64) return launch_dma2_cfg<OT, 64, 3>(a, s);
+    if (a.Cout <= 128) return launch_dma2_cfg<OT, 128, 3>(a, s);
+    return launch_dma2_cfg<OT, 256, 3>(a, s);
 }
 
 // bf16 operands only; out_dtype bf16 or f32.
@@ -279,3 +358,5 @@ int launch_conv_igemm_dma2(const ConvArgs &a, hipStream_t s) {
 }
 
 }  // namespace ymx
+
+YMX_STAMP_EXPORT(ymx_debug_stamps_dma2)

@@ -37,3 +37,39 @@ __device__ __forceinline__ void lds_dma16(const i32x4_t rsrc, unsigned lds_addr,
 }
 
 }  // namespace ymx
+
+// ---- in-kernel time stamps (diagnostic build only: make stamps) -----------------------
+// With YMX_STAMPS defined, thread 0 of each of the first YMX_STAMP_BLOCKS workgroups
+// records the shader clock at up to 8 points into a buffer nothing else reads;
+// ymx_debug_stamps() copies it out.  Slot 7 holds the 100 MHz wall clock at slot 0's time
+// and slot 6 at the last stamp, which gives the shader clock rate.  The product build
+// defines none of this.
+#ifdef YMX_STAMPS
+#define YMX_STAMP_BLOCKS 16384
+namespace ymx {
+static __device__ unsigned long long ymx_stamp_buf[YMX_STAMP_BLOCKS * 8];
+}
+#define YMX_STAMP(k)                                                                        \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < YMX_STAMP_BLOCKS) {                            \
+            ymx::ymx_stamp_buf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();        \
+            if ((k) == 0) ymx::ymx_stamp_buf[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                   \
+    } while (0)
+#define YMX_STAMP_END(k)                                                                    \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < YMX_STAMP_BLOCKS) {                            \
+            ymx::ymx_stamp_buf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();        \
+            ymx::ymx_stamp_buf[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();      \
+        }                                                                                   \
+    } while (0)
+#define YMX_STAMP_EXPORT(fn)                                                                \
+    extern "C" int fn(void *host, size_t bytes) {                                           \
+        if (bytes > sizeof(unsigned long long) * YMX_STAMP_BLOCKS * 8) return -1;           \
+        return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ymx::ymx_stamp_buf), bytes);       \
+    }
+#else
+#define YMX_STAMP(k) do { } while (0)
+#define YMX_STAMP_END(k) do { } while (0)
+#define YMX_STAMP_EXPORT(fn)
+#endif
