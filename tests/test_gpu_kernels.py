@@ -177,7 +177,7 @@ def test_conv_dma_kernel_forced(case):
         y_small = layer(xin, residual=rin)
         _lib.check(L.ymx_set_option(b"dma_min_tiles", 0))
         _lib.check(L.ymx_set_option(b"dma_narrow", 1))
-        for variant in (1, 2):       # 256x256 tile / 1 workgroup per CU, 256x128 tile / 2 per CU
+        for variant in (1, 2, 3, 4):  # 256x256 two-stage / 256x128 two workgroups per CU / four-stage ring / staggered groups
             _lib.check(L.ymx_set_option(b"dma_variant", variant))
             y = layer(xin, residual=rin)
             y32 = layer(xin, residual=rin, out_dtype=torch.float32)

@@ -17,7 +17,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolo_amd import _lib                      # noqa: E402
 
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libymx_stamps.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get("YMX_STAMP_LIB", "libymx_stamps.so"))
 from yolo_amd.layers import YOLOConv            # noqa: E402
 
 NBLK = 16384
@@ -30,11 +30,11 @@ def main():
     use_res = "res" in sys.argv[3:]
     L = _lib.lib()
     handle = ctypes.CDLL(_lib.LIB_PATH)
-    reader = getattr(handle, "ymx_debug_stamps_" + ("dma2" if kern.startswith("dma2") else "dma1"))
+    reader = getattr(handle, "ymx_debug_stamps_" + kern[:4])
     reader.restype = ctypes.c_int
     reader.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     _lib.check(L.ymx_set_option(b"dma_min_tiles", 0))
-    _lib.check(L.ymx_set_option(b"dma_variant", 2 if kern.startswith("dma2") else 1))
+    _lib.check(L.ymx_set_option(b"dma_variant", int(kern[3])))
     _lib.check(L.ymx_set_option(b"dma_stages", 4 if kern.endswith("s4") else 3))
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, H, W, cin, generator=g).cuda().bfloat16()

@@ -81,6 +81,8 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
     a.K = k * k * Cin;
     set_fastdiv((unsigned)(a.OH * a.OW), a.ohw_m, a.ohw_s);
     set_fastdiv((unsigned)a.OW, a.ow_m, a.ow_s);
+    set_fastdiv((unsigned)Cin, a.cin_m, a.cin_s);
+    set_fastdiv((unsigned)k, a.k_m, a.k_s);
     a.act = act;
     a.dtype = dtype; a.x_dtype = x_dtype; a.out_dtype = out_dtype;
     if (conv_uses_mfma(Cin, dtype)) {
@@ -102,7 +104,10 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         // and has enough of them to occupy the chip; the 128x128 kernel otherwise.
         if (dtype == YMX_BF16 && Cout > 128) {
             const long long tiles = ((long long)(a.P + 255) / 256) * ((Cout + 255) / 256);
-            if (tiles >= dma_min_tiles()) return g_dma_variant == 1 ? launch_conv_igemm_dma(a, s) : launch_conv_igemm_dma2(a, s);
+            if (tiles >= dma_min_tiles())
+                return g_dma_variant == 1 ? launch_conv_igemm_dma(a, s)
+                     : g_dma_variant == 2 ? launch_conv_igemm_dma2(a, s)
+                     : g_dma_variant == 3 ? launch_conv_igemm_dma3(a, s) : launch_conv_igemm_dma4(a, s);
         }
         // Narrow layers (the first backbone stages): memory-bound; the several-workgroups-
         // per-CU LDS-DMA kernel with channel tiles of 32/64/128.
@@ -137,7 +142,7 @@ int ymx_set_option(const char *name, long long value) {
         return YMX_OK;
     }
     if (!strcmp(name, "dma_variant")) {
-        if (value != 1 && value != 2) return fail(YMX_EARG, "set_option: dma_variant must be 1 or 2");
+        if (value < 1 || value > 4) return fail(YMX_EARG, "set_option: dma_variant must be 1..4");
         g_dma_variant = value;
         return YMX_OK;
     }

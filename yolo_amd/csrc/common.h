@@ -60,6 +60,20 @@ __device__ __forceinline__ float mish_f(float x) {
     const float n = e * (e + 2.0f);
     return x * (n * __builtin_amdgcn_rcpf(n + 2.0f));
 }
+// Two values at once: the multiplies and adds become packed fp32 instructions (v_pk_mul_f32,
+// v_pk_add_f32: two IEEE-exact results per issue slot), the exponential and the reciprocal
+// stay scalar.  Bit-identical to mish_f on each element.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t mish2_f(f32x2_t x) {
+#pragma clang fp contract(off)
+    const f32x2_t c = {fminf(x.x, 20.0f), fminf(x.y, 20.0f)};
+    const f32x2_t t = c * 1.44269504088896f;
+    const f32x2_t e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    const f32x2_t n = e * (e + 2.0f);
+    const f32x2_t d = n + 2.0f;
+    const f32x2_t r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    return x * (n * r);
+}
 __device__ __forceinline__ float act_f(float v, int act) {
 #pragma clang fp contract(off)
     if (act == YMX_ACT_MISH) return mish_f(v);
@@ -71,6 +85,13 @@ template <int ACT> __device__ __forceinline__ float act_c(float v) {
     if constexpr (ACT == YMX_ACT_MISH) return mish_f(v);
     if constexpr (ACT == YMX_ACT_LEAKY) return v > 0.0f ? v : 0.1f * v;
     return v;
+}
+// act(v * sc + sh) for a pair (the affine step is one packed fma, as in affine_f).
+template <int ACT> __device__ __forceinline__ f32x2_t affine_act2(f32x2_t v, f32x2_t sc, f32x2_t sh) {
+    const f32x2_t x = __builtin_elementwise_fma(v, sc, sh);
+    if constexpr (ACT == YMX_ACT_MISH) return mish2_f(x);
+    f32x2_t o = {act_c<ACT>(x.x), act_c<ACT>(x.y)};
+    return o;
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
@@ -92,6 +113,8 @@ struct ConvArgs {
     unsigned res_bytes;          // extent of the shortcut input in bytes (0: none, or beyond 4 GiB)
     unsigned ohw_m, ohw_s;       // p / (OH*OW) and p / OW for 0 <= p < 2^31 without a division:
     unsigned ow_m, ow_s;         //   m == 0 ? p : __umulhi(p, m) >> s   (set_fastdiv below)
+    unsigned cin_m, cin_s;       // same for K index / Cin (-> filter tap) and tap / k (-> tap row)
+    unsigned k_m, k_s;
 };
 
 // Multiply-shift division of a 31-bit dividend by d >= 1: with l = ceil(log2 d) and
@@ -136,6 +159,8 @@ static inline int packed_rows(int Cout) { return ((Cout + 127) / 128) * 128; }
 int launch_conv_igemm(const ConvArgs &a, hipStream_t s);
 int launch_conv_igemm_dma(const ConvArgs &a, hipStream_t s);
 int launch_conv_igemm_dma2(const ConvArgs &a, hipStream_t s);
+int launch_conv_igemm_dma3(const ConvArgs &a, hipStream_t s);
+int launch_conv_igemm_dma4(const ConvArgs &a, hipStream_t s);
 extern int g_dma2_stages;
 int launch_conv_direct(const ConvArgs &a, hipStream_t s);
 int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype,

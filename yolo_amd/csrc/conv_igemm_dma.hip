@@ -16,7 +16,7 @@
 //    hardware writes zeros into LDS: padding costs no branch and no memory traffic;
 //  - two LDS stages of (256 + TQ) x 128 B; the DMA of tile t+1 is issued before the
 //    MFMAs of tile t and waited for (vmcnt(0)) after them, one barrier per K step.
-#include "lds_dma.h"
+#include "conv_epilogue.h"
 
 namespace ymx {
 
@@ -31,8 +31,11 @@ conv_igemm_dma_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     constexpr int XBYTES = TP * 128, STAGE = (TP + TQ) * 128;
     constexpr unsigned OOB = 0x80000000u;
 
+    typedef EpiGeom<NI> Epi;
+
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    YMX_STAMP(0);
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wq = wave % WGQ, wp = wave / WGQ;
@@ -48,29 +51,8 @@ conv_igemm_dma_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     const int chunk = (lane & 7) ^ (srow & 7);          // K-chunk this lane fetches (swizzle)
     int xoff[NXI];
     unsigned xmask[NXI];
-    {
-        const int ohw = a.OH * a.OW;
 #pragma unroll
-        for (int i = 0; i < NXI; ++i) {
-            const int p = p0 + (wave * NXI + i) * 8 + srow;
-            int off = 0;
-            unsigned m = 0;
-            if (p < a.P) {
-                const int b = p / ohw, rem = p - b * ohw;
-                const int oh = rem / a.OW, ow = rem - oh * a.OW;
-                const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
-                off = ((b * a.H + ih0) * a.W + iw0) * a.x_ld;
-                for (int r = 0; r < a.k; ++r)
-                    for (int c = 0; c < a.k; ++c) {
-                        const bool ok = (unsigned)(ih0 + r) < (unsigned)a.H &&
-                                        (unsigned)(iw0 + c) < (unsigned)a.W;
-                        m |= (ok ? 1u : 0u) << (r * a.k + c);
-                    }
-            }
-            xoff[i] = off;
-            xmask[i] = m;
-        }
-    }
+    for (int i = 0; i < NXI; ++i) pixel_geometry(a, p0 + (wave * NXI + i) * 8 + srow, xoff[i], xmask[i]);
     int ci = chunk * 8, tap = 0, tr = 0, tc = 0;
     while (ci >= a.Cin) {
         ci -= a.Cin;
@@ -141,8 +123,16 @@ conv_igemm_dma_kernel(const ConvArgs a, const int ntile_q, const int nk) {
                 af[(i + 1) & 1][0] = *(const uint4 *)(base + a_off + (i + 1) * 2048 + swz0);
                 af[(i + 1) & 1][1] = *(const uint4 *)(base + a_off + (i + 1) * 2048 + swz1);
             }
+#ifdef YMX_EXP_NODMA
+            if (false) {
+#else
             if (more) {
+#endif
+#ifdef YMX_EXP_HALFX
+                if (i < NXI / 2) {
+#else
                 if (i < NXI) {
+#endif
                     const bool ok = (xmask[i] & tapbit) != 0;
                     const unsigned off = ok ? (unsigned)(xoff[i] + tapoff) * 2u : OOB;
                     lds_dma16(xrsrc, sbase + (unsigned)((wave * NXI + i) * 1024), off);
@@ -169,87 +159,28 @@ conv_igemm_dma_kernel(const ConvArgs a, const int ntile_q, const int nk) {
         __syncthreads();
     };
 
+    YMX_STAMP(1);
     dma(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) step(kt);
-
-    // ---- epilogue -------------------------------------------------------------------
-    // In the accumulator layout a lane owns 4 channels of one pixel per 16x16 tile, so a
-    // direct store touches 16 pixel rows with 32 contiguous bytes each.  LDS is free
-    // now, so every wave transposes its own tile privately (no workgroup barrier): per
-    // 64-channel half it writes act(acc*scale+shift) as fp32 rows [pixel][64 channels]
-    // (16-byte slots XOR-swizzled by the pixel index: conflict-free both ways), then
-    // reads them back with 16 lanes per pixel, adds the shortcut (loaded in the same
-    // pattern), rounds once and stores: 128 contiguous bytes per pixel per instruction.
-    OT *__restrict__ y = (OT *)a.y;
-    const bf16_t *__restrict__ res = (const bf16_t *)a.res;
-    const bool vec_ok = ((a.Cout & 3) == 0) && ((a.y_ld & 3) == 0) && (res == nullptr || (a.res_ld & 3) == 0);
-    static_assert(8 * WP * 256 <= 2 * STAGE, "per-wave transpose images must fit in LDS");
-    char *tbase = smem + wave * (WP * 256);
-    const int act = a.act;
+    YMX_STAMP(2);
+    for (int kt = 0; kt < nk - 1; ++kt) step(kt);
+    // first half of the shortcut input: in flight during the last K step (which issues no DMA)
+    const int cbase = q0 + wq * WQ, pbase = p0 + wp * WP;
+    epi_u32x4_t rpre[Epi::NH][Epi::NPASS];
+    if (epi_res_pre(a)) {
+        epi_load_res<NI>(a, 0, cbase, pbase, lane, rpre[0]);
+    } else {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int il = 0; il < NI / 2; ++il) {
-            const int i = half * (NI / 2) + il;
-            const int co = q0 + wq * WQ + i * 16 + 4 * (lane >> 4);
-            float sc[4], sh[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = co + r;
-                const bool in = c < a.Cout;
-                sc[r] = in ? (a.scale ? a.scale[c] : 1.0f) : 0.0f;
-                sh[r] = (in && a.shift) ? a.shift[c] : 0.0f;
-            }
-            const int slot = il * 4 + (lane >> 4);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                float4 v;
-                v.x = act_f(affine_f(acc[i][j][0], sc[0], sh[0]), act);
-                v.y = act_f(affine_f(acc[i][j][1], sc[1], sh[1]), act);
-                v.z = act_f(affine_f(acc[i][j][2], sc[2], sh[2]), act);
-                v.w = act_f(affine_f(acc[i][j][3], sc[3], sh[3]), act);
-                const int px = j * 16 + (lane & 15);
-                *(float4 *)(tbase + px * 256 + ((slot ^ (px & 15)) << 4)) = v;
-            }
-        }
-        // rows back out: lane -> pixel 4n + (lane >> 4), channels 4*(lane & 15) .. +3 of this half
-        const int slot = lane & 15;
-        const int co = q0 + wq * WQ + half * (WQ / 2) + slot * 4;
-#pragma unroll 4
-        for (int n = 0; n < WP / 4; ++n) {
-            const int px = n * 4 + (lane >> 4);
-            const int p = p0 + wp * WP + px;
-            float4 v = *(const float4 *)(tbase + px * 256 + ((slot ^ (px & 15)) << 4));
-            if (p >= a.P || co >= a.Cout) continue;
-            if (vec_ok) {
-                if (res) {
-                    const uint2 rv = *(const uint2 *)(res + (size_t)p * a.res_ld + co);
-                    v.x += __uint_as_float(rv.x << 16);
-                    v.y += __uint_as_float(rv.x & 0xffff0000u);
-                    v.z += __uint_as_float(rv.y << 16);
-                    v.w += __uint_as_float(rv.y & 0xffff0000u);
-                }
-                OT *yp = y + (size_t)p * a.y_ld + co;
-                if constexpr (sizeof(OT) == 2) {
-                    *(uint2 *)yp = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
-                } else {
-                    *(float4 *)yp = v;
-                }
-            } else {
-                const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (co + r < a.Cout) {
-                        float o = vv[r];
-                        if (res) o += bf16_to_f32(res[(size_t)p * a.res_ld + co + r]);
-                        elem<OT>::store(y + (size_t)p * a.y_ld + co + r, o);
-                    }
-                }
-            }
-        }
+        for (int n = 0; n < Epi::NPASS; ++n) rpre[0][n] = epi_u32x4_t{0u, 0u, 0u, 0u};
     }
+    step(nk - 1);
+    YMX_STAMP(3);
+
+    // ---- epilogue: per-wave transpose through LDS (conv_epilogue.h); LDS is free now ----
+    static_assert(8 * Epi::LDS_BYTES <= 2 * STAGE, "per-wave transpose images must fit in LDS");
+    epi_run<OT, NI, NJ>(a, acc, smem + wave * Epi::LDS_BYTES, cbase, pbase, lane, rpre);
+    YMX_STAMP_END(5);
 }
 
 template <typename OT, int TQ>
@@ -281,3 +212,5 @@ int launch_conv_igemm_dma(const ConvArgs &a, hipStream_t s) {
 }
 
 }  // namespace ymx
+
+YMX_STAMP_EXPORT(ymx_debug_stamps_dma1)

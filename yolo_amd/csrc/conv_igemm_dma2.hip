@@ -26,8 +26,7 @@
 // fragment reads (16 rows x one chunk per 16-lane group) touch 16 distinct slots of the
 // 256-byte bank row.  The swizzle is applied to the DMA's source address (the lane filling
 // slot s of row r fetches chunk s ^ f(r)), the LDS image itself stays linear.
-#include <type_traits>
-#include "lds_dma.h"
+#include "conv_epilogue.h"
 
 namespace ymx {
 
@@ -44,10 +43,7 @@ conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     constexpr int NPIECE = NXI + NWI;
     constexpr int XBYTES = TP * 64, STAGE = (TP + WROWS) * 64;
     constexpr int INFLIGHT = NPIECE * (NSTAGE - 2);             // pieces that may still be in flight at a step's end
-    constexpr int HQ = WQ < 64 ? WQ : 64, NH = WQ / HQ;          // epilogue: channel halves of <= 64
-    constexpr int SLOTS = HQ / 4, LPP = SLOTS / 2;               // 16-byte slots per fp32 row; lanes per pixel (8 channels each)
-    constexpr int PPI = 64 / LPP, NPASS = WP / PPI;              // pixels per store instruction; instructions per half
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    typedef EpiGeom<NI> Epi;
     constexpr unsigned OOB = 0x80000000u;
     // (the launcher sizes the dynamic LDS as max(pipeline stages, 4 per-wave transpose images))
 
@@ -105,32 +101,18 @@ conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
         }
     };
 
-    // ---- shortcut input: fetched now, in the store pattern of the epilogue, so that its
-    // latency is hidden behind the whole K loop (it is older than every DMA piece, so the
-    // counted waits below cover it as well)
-    const bf16_t *__restrict__ res = (const bf16_t *)a.res;
-    const bool vec_ok = ((a.Cout & 7) == 0) && ((a.y_ld & 7) == 0) && (res == nullptr || (a.res_ld & 7) == 0);
-    const bool res_pre = res != nullptr && vec_ok && a.res_bytes != 0;
-    const int sl = lane % LPP;                                   // epilogue: this lane's 8-channel group
-    const __amdgpu_buffer_rsrc_t rrsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void *)a.res, 0, res_pre ? (int)a.res_bytes : 0, 0x00020000);
-    auto load_res = [&](int half, u32x4_t (&r)[NPASS]) {
-        const int co = q0 + wq * WQ + half * HQ + sl * 8;
-#pragma unroll
-        for (int n = 0; n < NPASS; ++n) {
-            const int p = p0 + wp * WP + n * PPI + lane / LPP;
-            const unsigned off = (p < a.P && co < a.Cout) ? ((unsigned)p * (unsigned)a.res_ld + (unsigned)co) * 2u : OOB;
-            r[n] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
-        }
-    };
-    // 64-channel wave tiles fetch it here; 128-channel ones (short of registers) fetch the
-    // first half before the last K step and the second half during the epilogue
-    u32x4_t rpre[NH][NPASS];
-    if (res_pre && NH == 1) {
-        load_res(0, rpre[0]);
+    // ---- shortcut input: 64-channel wave tiles fetch it now, so that its latency hides
+    // behind the whole K loop (it is older than every DMA piece: the counted waits below
+    // cover it); 128-channel ones, short of registers, fetch the first half before the
+    // last K step and the second half during the epilogue
+    const int cbase = q0 + wq * WQ, pbase = p0 + wp * WP;
+    const bool res_pre = epi_res_pre(a);
+    epi_u32x4_t rpre[Epi::NH][Epi::NPASS];
+    if (res_pre && Epi::NH == 1) {
+        epi_load_res<NI>(a, 0, cbase, pbase, lane, rpre[0]);
     } else {
 #pragma unroll
-        for (int n = 0; n < NPASS; ++n) rpre[0][n] = u32x4_t{0u, 0u, 0u, 0u};
+        for (int n = 0; n < Epi::NPASS; ++n) rpre[0][n] = epi_u32x4_t{0u, 0u, 0u, 0u};
     }
 
     f32x4_t acc[NI][NJ];
@@ -178,136 +160,16 @@ conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
         st = st + 1 == NSTAGE ? 0 : st + 1;
     };
     for (int s = 0; s < nk - 1; ++s) step(s);
-    if constexpr (NH == 2) {
-        if (res_pre) load_res(0, rpre[0]);               // older than the last step's pieces: the counted wait holds
+    if constexpr (Epi::NH == 2) {
+        if (res_pre) epi_load_res<NI>(a, 0, cbase, pbase, lane, rpre[0]);   // older than the last step's pieces
     }
     step(nk - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     YMX_STAMP(3);
 
-    // ---- epilogue: per-wave transpose through LDS ------------------------------------
-    // The raw accumulators go to LDS as fp32 rows [pixel][HQ channels] (16-byte slots
-    // XOR-swizzled by pixel); each lane then reads back 8 consecutive channels of one
-    // pixel, applies scale/shift, activation and shortcut, rounds once and stores 16
-    // bytes (bf16) -- a pixel's channels are one contiguous run per store instruction.
-    // The common case (16-byte aligned rows, shortcut prefetched or absent) is compiled
-    // once per activation so that the per-value code is branch-free.
-    OT *__restrict__ y = (OT *)a.y;
-    char *tbase = smem + wave * (WP * HQ * 4);
-    auto to_lds = [&](int half) {
-#pragma unroll
-        for (int il = 0; il < HQ / 16; ++il) {
-            const int slot = il * 4 + (lane >> 4);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int px = j * 16 + (lane & 15);
-                *(f32x4_t *)(tbase + px * (HQ * 4) + ((slot ^ (px & (SLOTS - 1))) << 4)) = acc[half * (HQ / 16) + il][j];
-            }
-        }
-    };
-    auto read_row = [&](int px, float (&v)[8]) {
-        const char *row = tbase + px * (HQ * 4);
-        const int sw = px & (SLOTS - 1);
-        const float4 v0 = *(const float4 *)(row + (((2 * sl) ^ sw) << 4));
-        const float4 v1 = *(const float4 *)(row + (((2 * sl + 1) ^ sw) << 4));
-        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
-        v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-    };
-    auto load_affine = [&](int half, float (&sc)[8], float (&sh)[8]) {
-        const int co = q0 + wq * WQ + half * HQ + sl * 8;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int c = co + r;
-            const bool in = c < a.Cout;
-            sc[r] = in ? (a.scale ? a.scale[c] : 1.0f) : 0.0f;
-            sh[r] = (in && a.shift) ? a.shift[c] : 0.0f;
-        }
-    };
-
-    auto fast = [&](auto act_tag, auto res_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
-        constexpr bool RES = decltype(res_tag)::value;
-#pragma unroll
-        for (int half = 0; half < NH; ++half) {
-            float sc[8], sh[8];
-            if constexpr (RES && NH == 2) {
-                if (half == 1) load_res(1, rpre[NH - 1]);      // lands while the accumulators go to LDS
-            }
-            load_affine(half, sc, sh);
-            to_lds(half);
-            if (half == 0) YMX_STAMP(4);
-            const int co = q0 + wq * WQ + half * HQ + sl * 8;
-            float nxt[8];
-            read_row(lane / LPP, nxt);
-#pragma unroll
-            for (int n = 0; n < NPASS; ++n) {
-                const int px = n * PPI + lane / LPP;
-                const int p = p0 + wp * WP + px;
-                float v[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = nxt[r];
-                if (n + 1 < NPASS) read_row(px + PPI, nxt);     // next pass's row is in flight during this one's math
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = act_c<ACT>(affine_f(v[r], sc[r], sh[r]));
-                if constexpr (RES) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        // a separately rounded add (no fusing with the activation's last
-                        // multiply): every conv kernel must give the same bits
-                        v[2 * r] = __fadd_rn(v[2 * r], __uint_as_float(rpre[half][n][r] << 16));
-                        v[2 * r + 1] = __fadd_rn(v[2 * r + 1], __uint_as_float(rpre[half][n][r] & 0xffff0000u));
-                    }
-                }
-                if (p < a.P && co < a.Cout) {
-                    OT *yp = y + (size_t)p * a.y_ld + co;
-                    if constexpr (sizeof(OT) == 2) {
-                        *(uint4 *)yp = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]),
-                                                  pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
-                    } else {
-                        *(float4 *)yp = make_float4(v[0], v[1], v[2], v[3]);
-                        *(float4 *)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    auto fast_act = [&](auto res_tag) {
-        if (a.act == YMX_ACT_MISH) fast(std::integral_constant<int, YMX_ACT_MISH>{}, res_tag);
-        else if (a.act == YMX_ACT_LEAKY) fast(std::integral_constant<int, YMX_ACT_LEAKY>{}, res_tag);
-        else fast(std::integral_constant<int, YMX_ACT_NONE>{}, res_tag);
-    };
-
-    if (vec_ok && res == nullptr) {
-        fast_act(std::false_type{});
-    } else if (res_pre) {
-        fast_act(std::true_type{});
-    } else {
-        // odd channel counts or pixel strides (e.g. the 255-channel output layers)
-        const int act = a.act;
-        for (int half = 0; half < NH; ++half) {
-            float sc[8], sh[8];
-            load_affine(half, sc, sh);
-            to_lds(half);
-            const int co = q0 + wq * WQ + half * HQ + sl * 8;
-            for (int n = 0; n < NPASS; ++n) {
-                const int px = n * PPI + lane / LPP;
-                const int p = p0 + wp * WP + px;
-                float v[8];
-                read_row(px, v);
-                if (p >= a.P) continue;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    if (co + r < a.Cout) {
-                        float o = act_f(affine_f(v[r], sc[r], sh[r]), act);
-                        if (res) o += bf16_to_f32(res[(size_t)p * a.res_ld + co + r]);
-                        elem<OT>::store(y + (size_t)p * a.y_ld + co + r, o);
-                    }
-                }
-            }
-        }
-    }
+    // ---- epilogue: per-wave transpose through LDS (conv_epilogue.h) --------------------
+    epi_run<OT, NI, NJ>(a, acc, smem + wave * Epi::LDS_BYTES, cbase, pbase, lane, rpre);
     YMX_STAMP_END(5);
 }
 

@@ -1,0 +1,264 @@
+// bf16 implicit-GEMM convolution, 256 x 256 tile, phase-staggered wave groups (gfx950).
+//
+// Same mathematics, operand orientation and zero padding as conv_igemm_dma.hip (weights =
+// MFMA A operand, pixels = B, D[row = channel][col = pixel]; out-of-range buffer offsets
+// make the LDS-DMA write zeros), same 8-wave workgroup (2 x 4 waves of 128 channels x 64
+// pixels), same K order per accumulator -- results are bit-identical.  The K loop is
+// organised so that the matrix pipe of every SIMD always has a wave to serve:
+//
+//   groups    waves 0-3 and 4-7 (one of each per SIMD) run the same phase sequence one
+//             barrier apart: while one group issues its 16 MFMAs of a phase, the other
+//             does the LDS reads and the DMA issue of its next phase
+//   phases    four per 64-deep K tile, one quadrant (64 channels x 32 pixels) of the wave
+//             tile each:  (m0,n0) (m0,n1) (m1,n1) (m1,n0);  a phase is
+//                 LDS reads of the fragments that change | issue one 16 KB DMA piece |
+//                 counted vmcnt | barrier | 16 MFMAs | barrier
+//   pieces    a K tile is staged as four 16 KB pieces in the order they are first read:
+//             W(m0) X(n0) X(n1) W(m1) -- the rows of all waves' first/second channel
+//             halves and pixel halves.  Eight slots (two K tiles) of LDS; piece c is
+//             issued in phase c-6 and waited for in phase c-2 (four pieces may stay in
+//             flight), is read from phase c-1 on, and its slot is re-issued two or more
+//             phases after its last read -- every reader has then passed a barrier behind
+//             its reads, every writer's data is behind a wait and a barrier.
+#include "conv_epilogue.h"
+
+namespace ymx {
+
+template <typename OT>
+__global__ void __launch_bounds__(512, 2)
+conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
+    constexpr int TP = 256, TQ = 256;
+    constexpr int WQ = 128, WP = 64;
+    constexpr int NI = WQ / 16, NJ = WP / 16;
+    constexpr int PIECE = 128 * 128;                        // 128 rows x 64 bf16
+    constexpr unsigned OOB = 0x80000000u;
+    typedef EpiGeom<NI> Epi;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    YMX_STAMP(0);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wq = wave & 1, wp = wave >> 1;                // wave tile position (as in the other kernels)
+    const int group = wave >> 2;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tq = id % ntile_q, tp = id / ntile_q;
+    const int p0 = tp * TP, q0 = tq * TQ;
+    const i32x4_t xrsrc = make_rsrc(a.x, a.x_bytes);
+    const i32x4_t wrsrc = make_rsrc(a.w, a.w_bytes);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+
+    // ---- DMA geometry ------------------------------------------------------------------
+    // A piece is 16 instructions of 8 rows x 128 B; this wave issues instructions 2*wave and
+    // 2*wave+1, i.e. piece rows 16*wave + 8*i + srow.  Row r of an X piece is pixel
+    // (r>>5)*64 + half*32 + (r&31) of the tile, row r of a W piece is channel
+    // (r>>6)*128 + half*64 + (r&63).  The lane that fills 16-byte slot s of a row fetches
+    // K-chunk s ^ (row & 7) (the swizzle the fragment reads undo).
+    const int srow = lane >> 3;
+    const int chunk = (lane & 7) ^ srow;
+    int xoff[2][2];         // [pixel half][instruction]
+    unsigned xmask[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = 16 * wave + 8 * i + srow;
+            pixel_geometry(a, p0 + (r >> 5) * 64 + h * 32 + (r & 31), xoff[h][i], xmask[h][i]);
+        }
+    unsigned woff[2];       // byte offset of this lane's chunk in K tile 0: [instruction], channel half 0
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 16 * wave + 8 * i + srow;
+        woff[i] = (unsigned)(((q0 + (r >> 6) * 128 + (r & 63)) * a.Kw + chunk * 8) * 2);
+    }
+    const unsigned whalf = (unsigned)(64 * a.Kw * 2);       // channel half 1 = 64 rows further
+
+    // Issue piece `pos` (0: W(m0), 1: X(n0), 2: X(n1), 3: W(m1)) of K tile kt into its slot.
+    // Tiles past the end of K and taps outside the image use out-of-range offsets.
+    int tapoff = 0;
+    unsigned tapbit = 0;
+    auto issue = [&](int kt, auto pos_tag) {
+        constexpr int POS = decltype(pos_tag)::value;
+        const unsigned sbase = lds0 + (unsigned)(((kt & 1) * 4 + POS) * PIECE + wave * 2048);
+        if constexpr (POS == 0 || POS == 3) {
+            const unsigned base = kt < nk ? (unsigned)kt * 128u + (POS == 3 ? whalf : 0u) : OOB;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lds_dma16(wrsrc, sbase + (unsigned)(i * 1024), kt < nk ? base + woff[i] : OOB);
+        } else {
+            if constexpr (POS == 1) {       // K index -> (tap, channel) -> (row, col), once per tile
+                const int kpos = kt * 64 + chunk * 8;
+                const int tap = fastdiv(kpos, a.cin_m, a.cin_s), ci = kpos - tap * a.Cin;
+                const int tr = fastdiv(tap, a.k_m, a.k_s), tc = tap - tr * a.k;
+                tapoff = (tr * a.W + tc) * a.x_ld + ci;
+                tapbit = tap < 32 ? (1u << tap) : 0u;
+            }
+            constexpr int H = POS - 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned off = (xmask[H][i] & tapbit) ? (unsigned)(xoff[H][i] + tapoff) * 2u : OOB;
+                lds_dma16(xrsrc, sbase + (unsigned)(i * 1024), off);
+            }
+        }
+    };
+
+    f32x4_t acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment reads: piece row = wave part + block*16 + (lane & 15); chunk kk*4 + (lane >> 4)
+    const int swz0 = (((lane >> 4)) ^ (lane & 7)) << 4;
+    const int swz1 = ((4 + (lane >> 4)) ^ (lane & 7)) << 4;
+    const int a_row = (wq * 64 + (lane & 15)) * 128;        // + ib * 2048 within W(m0) / W(m1)
+    const int b_row = (wp * 32 + (lane & 15)) * 128;        // + jb * 2048 within X(n0) / X(n1)
+
+    uint4 af[4][2];         // weight fragments of the current channel half: [block][kk]
+    uint4 bfr[2][2][2];     // pixel fragments: [pixel half][block][kk]
+
+    auto read_a = [&](int kt, int mh) {
+        const char *base = smem + ((kt & 1) * 4 + (mh ? 3 : 0)) * PIECE + a_row;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            af[ib][0] = *(const uint4 *)(base + ib * 2048 + swz0);
+            af[ib][1] = *(const uint4 *)(base + ib * 2048 + swz1);
+        }
+    };
+    auto read_b = [&](int kt, int nh) {
+        const char *base = smem + ((kt & 1) * 4 + 1 + nh) * PIECE + b_row;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            bfr[nh][jb][0] = *(const uint4 *)(base + jb * 2048 + swz0);
+            bfr[nh][jb][1] = *(const uint4 *)(base + jb * 2048 + swz1);
+        }
+    };
+    auto mfma_quadrant = [&](auto mh_tag, auto nh_tag) {
+        constexpr int MH = decltype(mh_tag)::value, NHALF = decltype(nh_tag)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    acc[MH * 4 + ib][NHALF * 2 + jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8_t, af[ib][kk]), __builtin_bit_cast(bf16x8_t, bfr[NHALF][jb][kk]),
+                        acc[MH * 4 + ib][NHALF * 2 + jb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+
+    // ---- prologue: pieces 0..5 in flight, pieces 0 and 1 landed --------------------------
+    issue(0, I0{});
+    issue(0, I1{});
+    issue(0, I2{});
+    issue(0, I3{});
+    issue(1, I0{});
+    issue(1, I1{});
+    YMX_STAMP(1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    YMX_STAMP(2);
+    if (group == 1) __builtin_amdgcn_s_barrier();          // second group runs one barrier behind
+
+    // A raw barrier (no implied drain of the memory counters) that the compiler may not move
+    // LDS reads across: a read hoisted over it would see a piece some wave has not waited for.
+    auto barrier = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // between the LDS reads / DMA issue of a phase and its MFMAs
+    auto gate = [&]() {
+#ifndef YMX_EXP_NOWAIT
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but the four youngest pieces are in
+#endif
+        barrier();
+    };
+#ifdef YMX_EXP_NODMA
+#define issue(...) ((void)0)
+#endif
+    for (int kt = 0; kt < nk; ++kt) {
+        // phase 0: quadrant (m0, n0); issue X(n1) of tile kt+1
+        read_a(kt, 0);
+        read_b(kt, 0);
+        issue(kt + 1, I2{});
+        gate();
+        mfma_quadrant(I0{}, I0{});
+        barrier();
+        // phase 1: quadrant (m0, n1); issue W(m1) of tile kt+1
+        read_b(kt, 1);
+        issue(kt + 1, I3{});
+        gate();
+        mfma_quadrant(I0{}, I1{});
+        barrier();
+        // phase 2: quadrant (m1, n1); issue W(m0) of tile kt+2
+        read_a(kt, 1);
+        issue(kt + 2, I0{});
+        gate();
+        mfma_quadrant(I1{}, I1{});
+        barrier();
+        // phase 3: quadrant (m1, n0), fragments already in registers; issue X(n0) of tile kt+2
+        issue(kt + 2, I1{});
+        gate();
+        mfma_quadrant(I1{}, I0{});
+        barrier();
+    }
+#ifdef YMX_EXP_NODMA
+#undef issue
+#endif
+    if (group == 0) barrier();
+
+    // first half of the shortcut input (the fragment registers are free now)
+    const int cbase = q0 + wq * WQ, pbase = p0 + wp * WP;
+    epi_u32x4_t rpre[Epi::NH][Epi::NPASS];
+    if (epi_res_pre(a)) {
+        epi_load_res<NI>(a, 0, cbase, pbase, lane, rpre[0]);
+    } else {
+#pragma unroll
+        for (int n = 0; n < Epi::NPASS; ++n) rpre[0][n] = epi_u32x4_t{0u, 0u, 0u, 0u};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    YMX_STAMP(3);
+
+    // ---- epilogue: per-wave transpose through LDS (conv_epilogue.h); LDS is free now ----
+    static_assert(8 * Epi::LDS_BYTES <= 8 * PIECE, "per-wave transpose images must fit in LDS");
+    epi_run<OT, NI, NJ>(a, acc, smem + wave * Epi::LDS_BYTES, cbase, pbase, lane, rpre);
+    YMX_STAMP_END(5);
+}
+
+template <typename OT>
+static int launch_dma4_cfg(const ConvArgs &a, hipStream_t s) {
+    constexpr int LDS = 8 * 128 * 128;
+    auto kern = conv_igemm_dma4_kernel<OT>;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(YMX_ELAUNCH, "conv_igemm_dma4: cannot reserve %d bytes of LDS", LDS);
+        }
+        configured = true;
+    }
+    const int ntile_p = (a.P + 255) / 256;
+    const int ntile_q = (a.Cout + 255) / 256;
+    const int nk = (a.K + 63) / 64;
+    const long long grid = (long long)ntile_p * ntile_q;
+    if (grid > 0x7fffffffLL) return fail(YMX_EUNSUPPORTED, "conv_igemm_dma4: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, a, ntile_q, nk);
+    return check_launch("conv_igemm_dma4");
+}
+
+// bf16 operands only; out_dtype bf16 or f32.
+int launch_conv_igemm_dma4(const ConvArgs &a, hipStream_t s) {
+    if (a.dtype != YMX_BF16) return fail(YMX_EUNSUPPORTED, "conv_igemm_dma4: bf16 operands only");
+    if (a.out_dtype == YMX_BF16) return launch_dma4_cfg<bf16_t>(a, s);
+    return launch_dma4_cfg<float>(a, s);
+}
+
+}  // namespace ymx
+
+YMX_STAMP_EXPORT(ymx_debug_stamps_dma4)
