@@ -40,14 +40,15 @@ def conv_kernel_name(op):
     bf16 = op.dtype == 1
     if (op.Cin % 8 if bf16 else op.Cin % 4):
         return "conv_direct"
-    if bf16 and op.Cout > 128:
-        # mirrors the choice in yolo_amd/csrc/api.hip: the large-tile LDS-DMA kernel when the
-        # layer has at least 160 tiles of 256 pixels x 256 channels
-        oh = op.H if op.stride == 1 else (op.H + 1 - op.k) // 2 + 1
-        ow = op.W if op.stride == 1 else (op.W + 1 - op.k) // 2 + 1
-        tiles = ((op.B * oh * ow + 255) // 256) * ((op.Cout + 255) // 256)
-        if tiles >= 160:
-            return "conv_igemm_dma_bf16_256x256"
+    # mirrors the choice in yolo_amd/csrc/api.hip (default options)
+    oh = op.H if op.stride == 1 else (op.H + 1 - op.k) // 2 + 1
+    ow = op.W if op.stride == 1 else (op.W + 1 - op.k) // 2 + 1
+    ptiles = (op.B * oh * ow + 255) // 256
+    if bf16 and op.Cout > 128 and ptiles * ((op.Cout + 255) // 256) >= 160:
+        return "conv_igemm_dma_bf16_256x256"          # large-tile LDS-DMA kernel
+    if bf16 and op.Cout <= 128 and ptiles >= 160:
+        tq = 32 if op.Cout <= 32 else (64 if op.Cout <= 64 else 128)
+        return "conv_igemm_dma2_bf16_%dx256" % tq     # narrow-layer LDS-DMA kernel, several workgroups per CU
     tile = "256x32" if op.Cout <= 32 else ("256x64" if op.Cout <= 64 else "128x128")
     return "conv_igemm_%s_%s" % ("bf16" if bf16 else "f32", tile)
 

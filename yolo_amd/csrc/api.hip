@@ -81,7 +81,10 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
     a.K = k * k * Cin;
     set_fastdiv((unsigned)(a.OH * a.OW), a.ohw_m, a.ohw_s);
     set_fastdiv((unsigned)a.OW, a.ow_m, a.ow_s);
-    set_fastdiv((unsigned)Cin, a.cin_m, a.cin_s);
+    a.CB = conv_channel_block(Cin);
+    a.kb = k * k * a.CB;
+    set_fastdiv((unsigned)a.kb, a.kb_m, a.kb_s);
+    set_fastdiv((unsigned)a.CB, a.cb_m, a.cb_s);
     set_fastdiv((unsigned)k, a.k_m, a.k_s);
     a.act = act;
     a.dtype = dtype; a.x_dtype = x_dtype; a.out_dtype = out_dtype;

@@ -113,7 +113,16 @@ struct ConvArgs {
     unsigned res_bytes;          // extent of the shortcut input in bytes (0: none, or beyond 4 GiB)
     unsigned ohw_m, ohw_s;       // p / (OH*OW) and p / OW for 0 <= p < 2^31 without a division:
     unsigned ow_m, ow_s;         //   m == 0 ? p : __umulhi(p, m) >> s   (set_fastdiv below)
-    unsigned cin_m, cin_s;       // same for K index / Cin (-> filter tap) and tap / k (-> tap row)
+    // K order of the implicit GEMM (= column order of the packed weights): channel blocks
+    // of CB channels outermost, then the k*k filter taps, then the channels of the block
+    //   K index = blk * (k*k*CB) + tap * CB + c,   input channel = blk * CB + c
+    // with CB = 64 when Cin is a multiple of 64 and CB = Cin (one block) otherwise.  Every
+    // MFMA kernel walks K in this order, so all of them add the same terms in the same
+    // order; the block-major order lets a kernel keep one block's input pixels in LDS and
+    // reuse them for all taps.
+    int CB, kb;                  // channel block, k*k*CB
+    unsigned kb_m, kb_s;         // fastdiv constants: K index / kb, (K index % kb) / CB, tap / k
+    unsigned cb_m, cb_s;
     unsigned k_m, k_s;
 };
 
@@ -130,6 +139,19 @@ static inline void set_fastdiv(unsigned d, unsigned &m, unsigned &s) {
 }
 __device__ __forceinline__ int fastdiv(int n, unsigned m, unsigned s) {
     return m == 0 ? n : (int)(__umulhi((unsigned)n, m) >> s);
+}
+
+static inline int conv_channel_block(int Cin) { return Cin % 64 == 0 ? 64 : Cin; }
+
+// K index (a multiple of the 16-byte chunk) -> element offset of its tap and channel
+// relative to a pixel's (ih0, iw0, 0), and the tap's bit for the validity masks of
+// pixel_geometry; indices past the end of K get no bit (their loads read zeros).
+__device__ __forceinline__ void k_decode(const ConvArgs &a, int kpos, int &tapoff, unsigned &tapbit) {
+    const int blk = fastdiv(kpos, a.kb_m, a.kb_s), rem = kpos - blk * a.kb;
+    const int tap = fastdiv(rem, a.cb_m, a.cb_s), ci = blk * a.CB + (rem - tap * a.CB);
+    const int tr = fastdiv(tap, a.k_m, a.k_s), tc = tap - tr * a.k;
+    tapoff = (tr * a.W + tc) * a.x_ld + ci;
+    tapbit = kpos < a.K ? (1u << tap) : 0u;
 }
 
 // Where output pixel p reads its input: element offset of (b, ih0, iw0, channel 0) -- it may

@@ -301,11 +301,14 @@ int launch_conv_direct(const ConvArgs &a, hipStream_t s) {
 // to 64] of T, row-major, zero padded; K order (r, c, ci) is HWIO's own flattening.
 template <typename T>
 __global__ void __launch_bounds__(256)
-pack_weights_kernel(const float *__restrict__ w, T *__restrict__ out, int K, int Cout, int Kw, int rows) {
+pack_weights_kernel(const float *__restrict__ w, T *__restrict__ out, int K, int Cin, int Cout, int Kw, int rows,
+                    int CB, int kb) {
     const size_t n = (size_t)rows * Kw;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int co = (int)(i / Kw), kk = (int)(i - (size_t)co * Kw);
-        const float v = (co < Cout && kk < K) ? w[(size_t)kk * Cout + co] : 0.0f;
+        // packed column kk = blk*kb + tap*CB + c  <-  HWIO row tap*Cin + blk*CB + c
+        const int blk = kk / kb, rem = kk - blk * kb, tap = rem / CB, c = rem - tap * CB;
+        const float v = (co < Cout && kk < K) ? w[(size_t)(tap * Cin + blk * CB + c) * Cout + co] : 0.0f;
         elem<T>::store(out + i, v);
     }
 }
@@ -329,13 +332,13 @@ int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int
                            dtype == YMX_BF16 ? 1 : 0);
         return check_launch("copy_weights");
     }
-    const int Kw = packed_kw(k, Cin), rows = packed_rows(Cout);
+    const int Kw = packed_kw(k, Cin), rows = packed_rows(Cout), CB = conv_channel_block(Cin);
     const size_t n = (size_t)rows * Kw;
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     if (dtype == YMX_BF16)
-        hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, w_hwio, (bf16_t *)w_packed, K, Cout, Kw, rows);
+        hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, w_hwio, (bf16_t *)w_packed, K, Cin, Cout, Kw, rows, CB, k * k * CB);
     else
-        hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, s, w_hwio, (float *)w_packed, K, Cout, Kw, rows);
+        hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, s, w_hwio, (float *)w_packed, K, Cin, Cout, Kw, rows, CB, k * k * CB);
     return check_launch("pack_weights");
 }
 

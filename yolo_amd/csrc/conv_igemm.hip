@@ -62,36 +62,8 @@ conv_igemm_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     const int lrow = t >> 3, chunk = t & 7;
     int xoff[NXL];          // element offset of (b, ih0, iw0, 0); may be negative
     unsigned xmask[NXL];    // bit (r*k+c): tap (r,c) of this pixel lies inside the image
-    {
-        const int ohw = a.OH * a.OW;
 #pragma unroll
-        for (int i = 0; i < NXL; ++i) {
-            const int p = p0 + lrow + 32 * i;
-            int off = 0;
-            unsigned m = 0;
-            if (p < a.P) {
-                const int b = p / ohw, rem = p - b * ohw;
-                const int oh = rem / a.OW, ow = rem - oh * a.OW;
-                const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
-                off = ((b * a.H + ih0) * a.W + iw0) * a.x_ld;
-                for (int r = 0; r < a.k; ++r)
-                    for (int c = 0; c < a.k; ++c) {
-                        const bool ok = (unsigned)(ih0 + r) < (unsigned)a.H &&
-                                        (unsigned)(iw0 + c) < (unsigned)a.W;
-                        m |= (ok ? 1u : 0u) << (r * a.k + c);
-                    }
-            }
-            xoff[i] = off;
-            xmask[i] = m;
-        }
-    }
-    // this lane's position along K: tap (tr, tc) and channel ci of its chunk
-    int ci = chunk * KCH, tap = 0, tr = 0, tc = 0;
-    while (ci >= a.Cin) {
-        ci -= a.Cin;
-        ++tap;
-        if (++tc == a.k) { tc = 0; ++tr; }
-    }
+    for (int i = 0; i < NXL; ++i) pixel_geometry(a, p0 + lrow + 32 * i, xoff[i], xmask[i]);
     const T *wsrc = w + (size_t)(q0 + lrow) * a.Kw + chunk * KCH;
     const int st_off = lrow * 128 + ((chunk ^ (lrow & 7)) << 4);
 
@@ -102,8 +74,9 @@ conv_igemm_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     Regs ra, rb;
 
     auto gload = [&](Regs &r, int kt) {
-        const int tapoff = (tr * a.W + tc) * a.x_ld + ci;
-        const unsigned tapbit = tap < 32 ? (1u << tap) : 0u;
+        int tapoff;
+        unsigned tapbit;
+        k_decode(a, kt * BK + chunk * KCH, tapoff, tapbit);     // this lane's tap and channel in tile kt
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
             const bool ok = (xmask[i] & tapbit) != 0;
@@ -114,12 +87,6 @@ conv_igemm_kernel(const ConvArgs a, const int ntile_q, const int nk) {
 #pragma unroll
         for (int i = 0; i < NWL; ++i)
             r.w[i] = *(const uint4 *)(wsrc + (size_t)i * 32 * a.Kw + (size_t)ktw * BK);
-        ci += BK;
-        while (ci >= a.Cin) {
-            ci -= a.Cin;
-            ++tap;
-            if (++tc == a.k) { tc = 0; ++tr; }
-        }
     };
     auto lstore = [&](const Regs &r, int buf) {
         char *xs = smem + buf * STAGE + st_off;

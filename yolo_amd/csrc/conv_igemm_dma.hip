@@ -53,20 +53,15 @@ conv_igemm_dma_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     unsigned xmask[NXI];
 #pragma unroll
     for (int i = 0; i < NXI; ++i) pixel_geometry(a, p0 + (wave * NXI + i) * 8 + srow, xoff[i], xmask[i]);
-    int ci = chunk * 8, tap = 0, tr = 0, tc = 0;
-    while (ci >= a.Cin) {
-        ci -= a.Cin;
-        ++tap;
-        if (++tc == a.k) { tc = 0; ++tr; }
-    }
     // byte offset of this lane's weight chunk in tile 0, piece 0 of this wave
     const unsigned woff0 = (unsigned)(((q0 + wave * NWI * 8 + srow) * a.Kw + chunk * 8) * 2);
     const unsigned wpiece = (unsigned)(8 * a.Kw * 2);
 
     auto dma = [&](int kt, int stage) {
         const unsigned sbase = lds0 + (unsigned)(stage * STAGE);
-        const int tapoff = (tr * a.W + tc) * a.x_ld + ci;
-        const unsigned tapbit = tap < 32 ? (1u << tap) : 0u;
+        int tapoff;
+        unsigned tapbit;
+        k_decode(a, kt * 64 + chunk * 8, tapoff, tapbit);
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
             const bool ok = (xmask[i] & tapbit) != 0;
@@ -77,12 +72,6 @@ conv_igemm_dma_kernel(const ConvArgs a, const int ntile_q, const int nk) {
         for (int i = 0; i < NWI; ++i)
             lds_dma16(wrsrc, sbase + (unsigned)(XBYTES + (wave * NWI + i) * 1024),
                       woff0 + (unsigned)i * wpiece + (unsigned)kt * 128u);
-        ci += 64;
-        while (ci >= a.Cin) {
-            ci -= a.Cin;
-            ++tap;
-            if (++tc == a.k) { tc = 0; ++tr; }
-        }
     };
 
     f32x4_t acc[NI][NJ];
@@ -106,8 +95,9 @@ conv_igemm_dma_kernel(const ConvArgs a, const int ntile_q, const int nk) {
         const char *base = smem + (kt & 1) * STAGE;
         const bool more = kt + 1 < nk;
         const unsigned sbase = lds0 + (unsigned)(((kt + 1) & 1) * STAGE);
-        const int tapoff = (tr * a.W + tc) * a.x_ld + ci;
-        const unsigned tapbit = tap < 32 ? (1u << tap) : 0u;
+        int tapoff;
+        unsigned tapbit;
+        k_decode(a, (kt + 1) * 64 + chunk * 8, tapoff, tapbit);
         const unsigned wstep = woff0 + (unsigned)(kt + 1) * 128u;
 
         uint4 bfr[2][NJ], af[2][2];
@@ -148,12 +138,6 @@ conv_igemm_dma_kernel(const ConvArgs a, const int ntile_q, const int nk) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8_t, af[i & 1][kk]), __builtin_bit_cast(bf16x8_t, bfr[kk][j]), acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
-        }
-        ci += 64;
-        while (ci >= a.Cin) {
-            ci -= a.Cin;
-            ++tap;
-            if (++tc == a.k) { tc = 0; ++tr; }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -67,22 +67,17 @@ conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     unsigned xmask[NXI];
 #pragma unroll
     for (int i = 0; i < NXI; ++i) pixel_geometry(a, p0 + (wave * NXI + i) * 16 + srow, xoff[i], xmask[i]);
-    int ci = chunk * 8, tap = 0, tr = 0, tc = 0;
-    while (ci >= a.Cin) {
-        ci -= a.Cin;
-        ++tap;
-        if (++tc == a.k) { tc = 0; ++tr; }
-    }
     const unsigned woff0 = (unsigned)(((q0 + wave * NWI * 16 + srow) * a.Kw + chunk * 8) * 2);
     const unsigned wpiece = (unsigned)(16 * a.Kw * 2);
 
-    // issue this wave's DMA pieces of tile kt into `stage`, then advance its K position.
+    // issue this wave's DMA pieces of tile kt into `stage`.
     // Tiles past the end use out-of-range offsets (zero fill, no traffic), so every
     // step issues the same number of pieces and the counted wait below is exact.
     auto dma = [&](int kt, int stage) {
         const unsigned sbase = lds0 + (unsigned)(stage * STAGE);
-        const int tapoff = (tr * a.W + tc) * a.x_ld + ci;
-        const unsigned tapbit = tap < 32 ? (1u << tap) : 0u;
+        int tapoff;
+        unsigned tapbit;
+        k_decode(a, kt * 32 + chunk * 8, tapoff, tapbit);
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
             const bool ok = (xmask[i] & tapbit) != 0;
@@ -93,12 +88,6 @@ conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
 #pragma unroll
         for (int i = 0; i < NWI; ++i)
             lds_dma16(wrsrc, sbase + (unsigned)(XBYTES + (wave * NWI + i) * 1024), wk + (unsigned)i * wpiece);
-        ci += 32;
-        while (ci >= a.Cin) {
-            ci -= a.Cin;
-            ++tap;
-            if (++tc == a.k) { tc = 0; ++tr; }
-        }
     };
 
     // ---- shortcut input: 64-channel wave tiles fetch it now, so that its latency hides

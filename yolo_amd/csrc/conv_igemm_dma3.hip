@@ -62,11 +62,9 @@ conv_igemm_dma3_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     int issue_kt = 0;
     unsigned xo[NXI], wo;
     auto dma_prepare = [&]() {
-        const int kpos = issue_kt * 32 + chunk * 8;
-        const int tap = fastdiv(kpos, a.cin_m, a.cin_s), ci = kpos - tap * a.Cin;
-        const int tr = fastdiv(tap, a.k_m, a.k_s), tc = tap - tr * a.k;
-        const int tapoff = (tr * a.W + tc) * a.x_ld + ci;
-        const unsigned tapbit = tap < 32 ? (1u << tap) : 0u;
+        int tapoff;
+        unsigned tapbit;
+        k_decode(a, issue_kt * 32 + chunk * 8, tapoff, tapbit);
 #pragma unroll
         for (int i = 0; i < NXI; ++i) xo[i] = (xmask[i] & tapbit) ? (unsigned)(xoff[i] + tapoff) * 2u : OOB;
         wo = issue_kt < nk ? woff0 + (unsigned)issue_kt * 64u : OOB;

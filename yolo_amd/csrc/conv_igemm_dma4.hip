@@ -86,11 +86,7 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
             for (int i = 0; i < 2; ++i) lds_dma16(wrsrc, sbase + (unsigned)(i * 1024), kt < nk ? base + woff[i] : OOB);
         } else {
             if constexpr (POS == 1) {       // K index -> (tap, channel) -> (row, col), once per tile
-                const int kpos = kt * 64 + chunk * 8;
-                const int tap = fastdiv(kpos, a.cin_m, a.cin_s), ci = kpos - tap * a.Cin;
-                const int tr = fastdiv(tap, a.k_m, a.k_s), tc = tap - tr * a.k;
-                tapoff = (tr * a.W + tc) * a.x_ld + ci;
-                tapbit = tap < 32 ? (1u << tap) : 0u;
+                k_decode(a, kt * 64 + chunk * 8, tapoff, tapbit);
             }
             constexpr int H = POS - 1;
 #pragma unroll
