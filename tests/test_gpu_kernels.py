@@ -140,6 +140,9 @@ DMA_SHAPES = [
     (2, 26, 26, 768, 512, 1, False, "leaky", False),     # Cin not a power of two
     (1, 9, 11, 32, 384, 3, False, "mish", True),         # Cin 32 (two taps per K step), 1.5 tiles
     (1, 33, 31, 8, 200, 5, False, None, False),          # 5x5, Cin 8, several pixel tiles
+    (3, 13, 13, 128, 256, 3, False, "mish", True),       # 3x3 stride 1, whole 64-channel blocks: the resident-slab kernel
+    (2, 26, 52, 64, 512, 3, False, "leaky", False),      # one channel block, W = 52, two channel tiles
+    (1, 7, 59, 192, 136, 3, False, None, True),          # widest supported row, partial channel tile
     # narrow layers: the several-workgroups-per-CU kernel with 128/64/32-channel tiles
     (2, 24, 20, 64, 128, 3, False, "mish", True),
     (1, 31, 33, 32, 64, 3, True, "mish", False),         # stride 2, one tap per K step
@@ -177,7 +180,7 @@ def test_conv_dma_kernel_forced(case):
         y_small = layer(xin, residual=rin)
         _lib.check(L.ymx_set_option(b"dma_min_tiles", 0))
         _lib.check(L.ymx_set_option(b"dma_narrow", 1))
-        for variant in (1, 2, 3, 4):  # 256x256 two-stage / 256x128 two workgroups per CU / four-stage ring / staggered groups
+        for variant in (1, 2, 3, 4, 5):  # two-stage / two workgroups per CU / four-stage ring / staggered groups / resident input slab (3x3)
             _lib.check(L.ymx_set_option(b"dma_variant", variant))
             y = layer(xin, residual=rin)
             y32 = layer(xin, residual=rin, out_dtype=torch.float32)
@@ -186,7 +189,7 @@ def test_conv_dma_kernel_forced(case):
             assert torch.equal(y, y_small), variant
     finally:
         _lib.check(L.ymx_set_option(b"dma_min_tiles", 160))
-        _lib.check(L.ymx_set_option(b"dma_variant", 1))
+        _lib.check(L.ymx_set_option(b"dma_variant", 5))
 
 
 def test_layers_standalone():

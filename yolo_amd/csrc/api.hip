@@ -35,7 +35,7 @@ static bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 // Fewest 256x256 tiles for which the large-tile kernel is chosen (one workgroup per CU,
 // 256 CUs).  YMX_DMA_MIN_TILES overrides it for experiments (a huge value disables the
 // kernel, 0 forces it).
-static long long g_dma_variant = 1;      // wide layers: 1 = 256x256 tile, 1 workgroup/CU; 2 = 256x128 tile, 2 workgroups/CU
+static long long g_dma_variant = 5;      // wide layers: 5 = resident-slab kernel for 3x3 stride 1 and the two-stage 256x256 kernel otherwise; 1-4: see ymx_set_option
 static long long g_dma_narrow = 1;       // layers of <= 128 output channels: 1 = LDS-DMA kernel, 0 = register-staged kernel
 static long long g_dma_min_tiles = -1;
 static long long dma_min_tiles() {
@@ -107,8 +107,9 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         // and has enough of them to occupy the chip; the 128x128 kernel otherwise.
         if (dtype == YMX_BF16 && Cout > 128) {
             const long long tiles = ((long long)(a.P + 255) / 256) * ((Cout + 255) / 256);
+            if (tiles >= dma_min_tiles() && g_dma_variant == 5 && conv_halo_eligible(a)) return launch_conv_igemm_halo(a, s);
             if (tiles >= dma_min_tiles())
-                return g_dma_variant == 1 ? launch_conv_igemm_dma(a, s)
+                return (g_dma_variant == 1 || g_dma_variant == 5) ? launch_conv_igemm_dma(a, s)
                      : g_dma_variant == 2 ? launch_conv_igemm_dma2(a, s)
                      : g_dma_variant == 3 ? launch_conv_igemm_dma3(a, s) : launch_conv_igemm_dma4(a, s);
         }
@@ -145,7 +146,7 @@ int ymx_set_option(const char *name, long long value) {
         return YMX_OK;
     }
     if (!strcmp(name, "dma_variant")) {
-        if (value < 1 || value > 4) return fail(YMX_EARG, "set_option: dma_variant must be 1..4");
+        if (value < 1 || value > 5) return fail(YMX_EARG, "set_option: dma_variant must be 1..5");
         g_dma_variant = value;
         return YMX_OK;
     }

@@ -1,0 +1,296 @@
+// bf16 3x3 stride-1 convolution, 256 x 256 tile, input pixels resident in LDS across the
+// nine filter taps (gfx950).
+//
+// The LDS-DMA kernels of conv_igemm_dma*.hip move (256 pixels + 256 channels) x 64 K per
+// 64-deep K tile from L2 into LDS, about 32 B per clock per CU at full MFMA rate -- which is
+// what one CU can pull from its L2, so the copy and the matrix pipe share the critical path.
+// Half of those bytes are input pixels, and for a 3x3 convolution they are the same pixels
+// nine times over, shifted by one row or column.  This kernel stages them once:
+//
+//   K order    channel blocks of 64 outermost, the nine taps inside (the order of the
+//              packed weights, see common.h), so one block of input channels serves nine
+//              consecutive K tiles
+//   slab       for a tile of 256 consecutive output pixels (row-major over images, rows,
+//              columns) and one channel block, the inputs of all nine taps are the
+//              contiguous pixel run [p0 - W - 1, p0 + 255 + W + 1]: 256 + 2W + 2 rows of
+//              128 B.  Tap (r, c) of output pixel p0 + n reads slab row n + r*W + c.  Two
+//              slabs (current block, next block) stay in LDS; the next one is fetched in
+//              the background, one DMA instruction per wave per K tile
+//   padding    slab rows exist for every pixel of the run, so a tap that falls outside the
+//              image would read a real neighbour (the previous row's last pixel, the next
+//              image): for such (pixel, tap) pairs, known from the per-pixel validity masks
+//              of pixel_geometry, the fragment read is pointed at a zero-filled KB instead
+//   weights    streamed per K tile as in conv_igemm_dma4.hip: two 16 KB pieces W(m0), W(m1)
+//              (the waves' first and second 64 channels), four ring slots
+//   schedule   the phase-staggered wave groups of conv_igemm_dma4.hip: four phases per K
+//              tile (quadrants (m0,n0) (m0,n1) (m1,n1) (m1,n0)), one group does its LDS
+//              reads and DMA issue while the other issues its 16 MFMAs.  DMA per wave and
+//              K tile: 5 instructions instead of 8
+//
+// Per accumulator the K terms are added in the same order as in every other MFMA kernel
+// here, so the results are bit-identical to theirs.
+//
+// LDS: 2 slabs x ceil((258 + 2W) / 8) KB + 64 KB weight ring + 1 KB that absorbs the
+// no-op DMA instructions which keep the per-tile instruction count constant (the counted
+// vmcnt waits rely on it): W <= 59.
+#include "conv_epilogue.h"
+
+namespace ymx {
+
+template <typename OT>
+__global__ void __launch_bounds__(512, 2)
+conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const int npieces) {
+    constexpr int TP = 256, TQ = 256;
+    constexpr int WQ = 128, WP = 64;
+    constexpr int NI = WQ / 16, NJ = WP / 16;
+    constexpr int WPIECE = 128 * 128;                       // 128 channel rows x 64 bf16
+    constexpr unsigned OOB = 0x80000000u;
+    typedef EpiGeom<NI> Epi;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    YMX_STAMP(0);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wq = wave & 1, wp = wave >> 1;                // wave tile position (as in the other kernels)
+    const int group = wave >> 2;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tq = id % ntile_q, tp = id / ntile_q;
+    const int p0 = tp * TP, q0 = tq * TQ;
+    const int nk = ncb * 9;
+    const i32x4_t xrsrc = make_rsrc(a.x, a.x_bytes);
+    const i32x4_t wrsrc = make_rsrc(a.w, a.w_bytes);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    const int slab_bytes = npieces * 1024;
+    const unsigned ring0 = lds0 + 2u * (unsigned)slab_bytes;       // weight ring: slot (kt&1)*2 + half
+    const unsigned dump = ring0 + 4u * WPIECE;
+    const char *ring = smem + 2 * slab_bytes;
+
+    // ---- DMA geometry ------------------------------------------------------------------
+    // Every DMA instruction fills 8 rows x 128 B; the lane that fills 16-byte slot s of row
+    // `row` fetches K-chunk s ^ (row & 7), the swizzle the fragment reads undo.
+    const int srow = lane >> 3;
+    const int chunk = (lane & 7) ^ srow;
+    // slab piece i = slab rows 8i .. 8i+7 = input pixels p0 - W - 1 + 8i + srow (any image)
+    // (modular unsigned arithmetic: a pixel before the tensor wraps to an offset beyond it and reads zeros)
+    const unsigned slab_off0 = ((unsigned)(p0 - a.W - 1 + srow) * (unsigned)a.x_ld + (unsigned)(chunk * 8)) * 2u;
+    const unsigned slab_step = 16u * (unsigned)a.x_ld;                          // bytes from one piece to the next
+    // weight pieces as in conv_igemm_dma4.hip: this wave fills piece rows 16*wave + 8*i + srow,
+    // row r = channel (r>>6)*128 + half*64 + (r&63)
+    unsigned woff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 16 * wave + 8 * i + srow;
+        woff[i] = (unsigned)(((q0 + (r >> 6) * 128 + (r & 63)) * a.Kw + chunk * 8) * 2);
+    }
+    const unsigned whalf = (unsigned)(64 * a.Kw * 2);
+
+    auto issue_w = [&](int kt, int half) {
+        const unsigned sbase = ring0 + (unsigned)(((kt & 1) * 2 + half) * WPIECE + wave * 2048);
+        const unsigned base = (unsigned)kt * 128u + (half ? whalf : 0u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lds_dma16(wrsrc, sbase + (unsigned)(i * 1024), kt < nk ? base + woff[i] : OOB);
+    };
+    // slab piece `idx` of channel block cb into slab cb&1; out-of-range idx / cb: a no-op
+    // instruction (zeros into the spare KB) so that the instruction count stays constant
+    auto issue_slab = [&](int cb, int idx) {
+        const bool real = idx < npieces && cb < ncb;
+        const unsigned dst = real ? lds0 + (unsigned)((cb & 1) * slab_bytes + idx * 1024) : dump;
+        const unsigned src = real ? slab_off0 + (unsigned)idx * slab_step + (unsigned)cb * 128u : OOB;
+        lds_dma16(xrsrc, dst, src);
+    };
+
+    // ---- fragment geometry ---------------------------------------------------------------
+    // this lane's four pixels (16-pixel blocks j of the wave's 64) and which taps they have
+    unsigned fmask[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        int unused;
+        pixel_geometry(a, p0 + wp * WP + j * 16 + (lane & 15), unused, fmask[j]);
+    }
+    const int hb0 = wp * WP + (lane & 15);                  // slab row of block 0, tap (0, 0)
+    const int q4 = lane >> 4;
+    const int swz0 = ((q4) ^ (lane & 7)) << 4;              // weight rows: row & 7 == lane & 7
+    const int swz1 = ((4 + q4) ^ (lane & 7)) << 4;
+    const int a_row = (wq * 64 + (lane & 15)) * 128;
+
+    f32x4_t acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    uint4 af[4][2];         // weight fragments of the current channel half: [block][kk]
+    uint4 bfr[2][2][2];     // pixel fragments: [pixel half][block][kk]
+
+    auto read_a = [&](int kt, int mh) {
+        const char *base = ring + ((kt & 1) * 2 + mh) * WPIECE + a_row;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            af[ib][0] = *(const uint4 *)(base + ib * 2048 + swz0);
+            af[ib][1] = *(const uint4 *)(base + ib * 2048 + swz1);
+        }
+    };
+    // pixel half nh of the current tap: slab rows hb + (2*nh + jb) * 16.  Where the tap falls
+    // outside the image the lane reads the always-zero spare KB instead (one select on the
+    // address; lanes sharing that address are a broadcast, not a bank conflict)
+    const int zero_off = 2 * slab_bytes + 4 * WPIECE;
+    auto read_b = [&](int slab_off, int shift, int tap, int nh, int set, bool live) {
+        const int hb = hb0 + shift;
+        const int base = slab_off + hb * 128 + ((q4 ^ (hb & 7)) << 4);     // (hb + 16 j) & 7 == hb & 7
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const int j = nh * 2 + jb;
+#ifdef YMX_EXP_NOMASK
+            const bool ok = true;
+#else
+            const bool ok = live && ((fmask[j] >> tap) & 1u);
+#endif
+            const int off = ok ? base + j * 2048 : zero_off;
+            bfr[set][jb][0] = *(const uint4 *)(smem + off);
+            bfr[set][jb][1] = *(const uint4 *)(smem + (off ^ 64));          // chunk 4 + q4
+        }
+    };
+    auto mfma_quadrant = [&](auto mh_tag, auto nh_tag, auto set_tag) {
+        constexpr int MH = decltype(mh_tag)::value, NHALF = decltype(nh_tag)::value, SET = decltype(set_tag)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    acc[MH * 4 + ib][NHALF * 2 + jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8_t, af[ib][kk]), __builtin_bit_cast(bf16x8_t, bfr[SET][jb][kk]),
+                        acc[MH * 4 + ib][NHALF * 2 + jb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+
+    // A raw barrier (no implied drain of the memory counters) that the compiler may not move
+    // LDS reads across: a read hoisted over it would see data some wave has not waited for.
+    auto barrier = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- prologue: slab of block 0, weights of tile 0 and W(m0) of tile 1 --------------------
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) issue_slab(0, jj * 8 + wave);
+    lds_dma16(xrsrc, dump, OOB);                           // the spare KB starts out (and stays) zero
+    issue_w(0, 0);
+    issue_w(0, 1);
+    issue_w(1, 0);
+    YMX_STAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    barrier();
+    YMX_STAMP(2);
+    if (group == 1) barrier();                             // second group runs one barrier behind
+
+    // Per K tile each wave issues W(m1) of the next tile (phase 1), one slab-class instruction
+    // (phase 2) and W(m0) of the tile after next (phase 3): five instructions.  vmcnt(5)
+    // after the issue of phase 1 therefore means "W(m1) of this tile has landed" (read in
+    // phase 2), after the issue of phase 3 "W(m0) of the next tile has landed" (read in its
+    // phase 0); a slab instruction of K tile j is covered by the wait in phase 3 of tile j+1.
+    // Every slot is re-issued two or more phases after its last read.
+    // (Measured: spreading the pixel-fragment reads as (8, 4, 8, 4) per phase by reading the
+    // next tile's first half in phase 3 was 8 % slower than this (12, 4, 8, 0).)
+    int cb = 0, tap = 0;
+#ifdef YMX_EXP_NODMA
+#define issue_w(...) ((void)0)
+#define issue_slab(...) ((void)0)
+#endif
+    for (int kt = 0; kt < nk; ++kt) {
+        const int slab = (cb & 1) * slab_bytes;
+        const int tr = (tap * 11) >> 5;                     // tap / 3 for tap < 9
+        const int shift = tr * a.W + (tap - tr * 3);
+        // phase 0: quadrant (m0, n0)
+        read_a(kt, 0);
+        read_b(slab, shift, tap, 0, 0, true);
+        barrier();
+        mfma_quadrant(I0{}, I0{}, I0{});
+        barrier();
+        // phase 1: quadrant (m0, n1)
+        read_b(slab, shift, tap, 1, 1, true);
+        issue_w(kt + 1, 1);
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        barrier();
+        mfma_quadrant(I0{}, I1{}, I1{});
+        barrier();
+        // phase 2: quadrant (m1, n1); background fetch of the next block's slab
+        read_a(kt, 1);
+        issue_slab(tap < 6 ? cb + 1 : ncb, tap * 8 + wave);
+        barrier();
+        mfma_quadrant(I1{}, I1{}, I1{});
+        barrier();
+        // phase 3: quadrant (m1, n0), fragments already in registers
+        issue_w(kt + 2, 0);
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        barrier();
+        mfma_quadrant(I1{}, I0{}, I0{});
+        barrier();
+        if (++tap == 9) { tap = 0; ++cb; }
+    }
+#ifdef YMX_EXP_NODMA
+#undef issue_w
+#undef issue_slab
+#endif
+    if (group == 0) barrier();
+
+    // first half of the shortcut input (the fragment registers are free now)
+    const int cbase = q0 + wq * WQ, pbase = p0 + wp * WP;
+    epi_u32x4_t rpre[Epi::NH][Epi::NPASS];
+    if (epi_res_pre(a)) {
+        epi_load_res<NI>(a, 0, cbase, pbase, lane, rpre[0]);
+    } else {
+#pragma unroll
+        for (int n = 0; n < Epi::NPASS; ++n) rpre[0][n] = epi_u32x4_t{0u, 0u, 0u, 0u};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    YMX_STAMP(3);
+
+    // ---- epilogue: per-wave transpose through LDS (conv_epilogue.h); LDS is free now ----
+    epi_run<OT, NI, NJ>(a, acc, smem + wave * Epi::LDS_BYTES, cbase, pbase, lane, rpre);
+    YMX_STAMP_END(5);
+}
+
+// The shapes this kernel takes: 3x3, stride 1, whole 64-channel blocks, rows short enough
+// for two slabs to fit in LDS.
+bool conv_halo_eligible(const ConvArgs &a) {
+    return a.dtype == YMX_BF16 && a.k == 3 && a.stride == 1 && a.Cin % 64 == 0 && a.W <= 59;
+}
+
+template <typename OT>
+static int launch_halo_cfg(const ConvArgs &a, hipStream_t s) {
+    const int npieces = (256 + 2 * a.W + 2 + 7) / 8;
+    int lds = 2 * npieces * 1024 + 4 * 128 * 128 + 1024;
+    if (lds < 8 * EpiGeom<8>::LDS_BYTES) lds = 8 * EpiGeom<8>::LDS_BYTES;      // the epilogue's transpose images
+    auto kern = conv_igemm_halo_kernel<OT>;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(YMX_ELAUNCH, "conv_igemm_halo: cannot reserve 160 KB of LDS");
+        }
+        configured = true;
+    }
+    const int ntile_p = (a.P + 255) / 256;
+    const int ntile_q = (a.Cout + 255) / 256;
+    const long long grid = (long long)ntile_p * ntile_q;
+    if (grid > 0x7fffffffLL) return fail(YMX_EUNSUPPORTED, "conv_igemm_halo: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, a, ntile_q, a.Cin / 64, npieces);
+    return check_launch("conv_igemm_halo");
+}
+
+int launch_conv_igemm_halo(const ConvArgs &a, hipStream_t s) {
+    if (!conv_halo_eligible(a)) return fail(YMX_EUNSUPPORTED, "conv_igemm_halo: shape not supported");
+    if (a.out_dtype == YMX_BF16) return launch_halo_cfg<bf16_t>(a, s);
+    return launch_halo_cfg<float>(a, s);
+}
+
+}  // namespace ymx
+
+YMX_STAMP_EXPORT(ymx_debug_stamps_dma5)
