@@ -45,6 +45,8 @@ def conv_kernel_name(op):
     ow = op.W if op.stride == 1 else (op.W + 1 - op.k) // 2 + 1
     ptiles = (op.B * oh * ow + 255) // 256
     if bf16 and op.Cout > 128 and ptiles * ((op.Cout + 255) // 256) >= 160:
+        if op.k == 3 and op.stride == 1 and op.Cin % 64 == 0 and op.W <= 59:
+            return "conv_igemm_halo_bf16_256x256"     # 3x3: input pixels resident in LDS across the taps
         return "conv_igemm_dma_bf16_256x256"          # large-tile LDS-DMA kernel
     if bf16 and op.Cout <= 128 and ptiles >= 160:
         tq = 32 if op.Cout <= 32 else (64 if op.Cout <= 64 else 128)

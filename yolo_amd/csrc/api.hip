@@ -107,11 +107,21 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         // and has enough of them to occupy the chip; the 128x128 kernel otherwise.
         if (dtype == YMX_BF16 && Cout > 128) {
             const long long tiles = ((long long)(a.P + 255) / 256) * ((Cout + 255) / 256);
-            if (tiles >= dma_min_tiles() && g_dma_variant == 5 && conv_halo_eligible(a)) return launch_conv_igemm_halo(a, s);
-            if (tiles >= dma_min_tiles())
-                return (g_dma_variant == 1 || g_dma_variant == 5) ? launch_conv_igemm_dma(a, s)
-                     : g_dma_variant == 2 ? launch_conv_igemm_dma2(a, s)
-                     : g_dma_variant == 3 ? launch_conv_igemm_dma3(a, s) : launch_conv_igemm_dma4(a, s);
+            if (tiles >= dma_min_tiles()) {
+                switch (g_dma_variant) {
+                case 1: return launch_conv_igemm_dma(a, s);
+                case 2: return launch_conv_igemm_dma2(a, s);
+                case 3: return launch_conv_igemm_dma3(a, s);
+                case 4: return launch_conv_igemm_dma4(a, s);
+                default:
+                    // 3x3 stride 1: input pixels resident in LDS across the taps; long 1x1
+                    // layers (several rounds of tiles): phase-staggered wave groups; the
+                    // two-stage kernel for the rest (measured per shape class on MI355X)
+                    if (conv_halo_eligible(a)) return launch_conv_igemm_halo(a, s);
+                    if (k == 1 && tiles >= 600) return launch_conv_igemm_dma4(a, s);
+                    return launch_conv_igemm_dma(a, s);
+                }
+            }
         }
         // Narrow layers (the first backbone stages): memory-bound; the several-workgroups-
         // per-CU LDS-DMA kernel with channel tiles of 32/64/128.

@@ -6,18 +6,23 @@
 // asc) order without sorting the row:
 //   - every candidate is a 64-bit key  ord(score) << 32 | ~index,  so one unsigned
 //     compare gives the visiting order;
-//   - keys above the score threshold and above a rising floor are appended to an
-//     LDS buffer (wavefront ballot + one LDS atomic per wave);  when the buffer
-//     cannot take another chunk it is bitonic-sorted, cut to its best 512 keys, and
-//     the 512th key becomes the new floor.  At the end the buffer holds exactly the
-//     keys >= floor, sorted;
+//   - a first pass over the row builds a 1024-bin histogram of the candidates' score
+//     bits (LDS atomics); a suffix sum over it gives the highest bin edge above which
+//     at least 8 * per_class candidates lie, and that edge is the starting floor: the
+//     greedy pass rarely needs more than a few times per_class candidates, so most of
+//     a long row is never stored or sorted;
+//   - a second pass appends the keys above the score threshold and the floor to an
+//     LDS buffer (wavefront ballot + one LDS atomic per wave);  should the buffer
+//     still fill up (many equal scores in one bin) it is bitonic-sorted, cut to its
+//     best 512 keys, and the 512th key becomes the new floor.  At the end the buffer
+//     holds exactly the keys >= floor, sorted;
 //   - wave 0 then runs the greedy suppression over that list in batches of 64: a
 //     lane tests its candidate against every box kept so far (the kept boxes live
 //     one per lane in registers and are broadcast with readlane), a ballot gives
 //     the bit mask of still-alive lanes, and the mask is resolved leader by leader;
-//   - if the list runs out before per_class boxes are kept and keys were cut, the
+//   - if the list runs out before per_class boxes are kept and keys were left out, the
 //     scan repeats below the last visited key (a further tier).  The result is the
-//     exact greedy NMS for any input; the tiers only matter for speed.
+//     exact greedy NMS for any input; floor and tiers only matter for speed.
 // Kernel 2, one workgroup per image: bitonic-sorts the kept entries of all classes
 // by (score desc, class asc, index asc) in LDS and writes the first `total`.
 //
@@ -33,6 +38,7 @@ typedef unsigned int u32;
 constexpr int NMS_KEEP = 512;     // keys that survive a cut
 constexpr int NMS_BUF = 2048;     // LDS key buffer
 constexpr int NMS_CHUNK = 1024;   // candidates scanned between capacity checks
+constexpr int NMS_BINS = 1024;    // histogram bins of the floor search
 
 __device__ __forceinline__ u32 ord_bits(float s) {
     const u32 u = __float_as_uint(s);
@@ -72,8 +78,10 @@ __device__ __forceinline__ bool iou_gt(float ay1, float ax1, float ay2, float ax
 __global__ void __launch_bounds__(256)
 nms_class_kernel(const NmsArgs a) {
     __shared__ u64 buf[NMS_BUF];
+    __shared__ int hist[NMS_BINS];
+    __shared__ int s_wsum[4];
     __shared__ u64 s_last;
-    __shared__ int s_cnt, s_nkept;
+    __shared__ int s_cnt, s_nkept, s_cutbin;
 
     const int c = blockIdx.x, b = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63;
@@ -84,6 +92,17 @@ nms_class_kernel(const NmsArgs a) {
     const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int PC = a.per_class;
 
+    // Histogram geometry: bin = (ord(score) - ord(thr)) >> hshift, clamped to the top bin;
+    // scores normally lie in (thr, 1], anything above lands in the top bin.
+    const u32 ob_thr = ord_bits(a.score_thr);
+    int hshift = 0;
+    {
+        const u32 range = (a.score_thr < 1.0f) ? ord_bits(1.0f) - ob_thr : (1u << 23);
+        while ((range >> hshift) >= (u32)NMS_BINS) ++hshift;
+    }
+    int target = 8 * PC;
+    target = target < 64 ? 64 : (target > NMS_KEEP ? NMS_KEEP : target);
+
     // wave 0: kept box j lives in lane j
     float ky1 = 0.f, kx1 = 0.f, ky2 = 0.f, kx2 = 0.f, kar = 0.f;
     u64 kkey = 0;
@@ -91,10 +110,56 @@ nms_class_kernel(const NmsArgs a) {
     u64 ceil_key = ~0ull;           // keys must be < ceil_key
 
     for (;;) {   // one pass per tier
-        if (t == 0) s_cnt = 0;
+        // ---- starting floor: the highest bin edge with at least `target` candidates above it
+        for (int i = t; i < NMS_BINS; i += 256) hist[i] = 0;
+        if (t == 0) { s_cnt = 0; s_cutbin = 0; }
         __syncthreads();
-        u64 floor_key = 0;          // keys must be > floor_key
-        bool cut = false;
+        for (int base = 0; base < M; base += NMS_CHUNK) {
+            const int i0 = base + t * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i0 < M) v = *(const float4 *)(col + i0);
+            const float sv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = i0 + e;
+                const float s = sv[e];
+                const u32 ob = ord_bits(s);
+                const u64 key = ((u64)ob << 32) | (u64)(0xffffffffu - (u32)idx);
+                if (idx < M && s > a.score_thr && key < ceil_key) {
+                    const u32 bin = (ob - ob_thr) >> hshift;
+                    atomicAdd(&hist[bin < (u32)NMS_BINS ? bin : NMS_BINS - 1], 1);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            // thread t owns bins NMS_BINS-1-4t .. NMS_BINS-4-4t (descending); inclusive scan from the top
+            int h[4], local = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h[e] = hist[NMS_BINS - 1 - (4 * t + e)]; local += h[e]; }
+            int incl = local;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            if (lane == 63) s_wsum[t >> 6] = incl;
+            __syncthreads();
+            int before = incl - local;
+            for (int w = 0; w < (t >> 6); ++w) before += s_wsum[w];
+            // the first bin (from the top) at which the running count reaches the target
+            int run = before;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool was_below = run < target;
+                run += h[e];
+                if (was_below && run >= target) s_cutbin = NMS_BINS - 1 - (4 * t + e);
+            }
+            __syncthreads();
+        }
+        const int cutbin = s_cutbin;   // 0: fewer than `target` candidates in all, take everything
+        u64 floor_key = cutbin > 0 ? (((u64)(ob_thr + ((u32)cutbin << hshift))) << 32) - 1ull : 0ull;   // keys must be > floor_key
+        bool cut = cutbin > 0;
         for (int base = 0; base < M; base += NMS_CHUNK) {
             const int i0 = base + t * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
