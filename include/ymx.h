@@ -138,6 +138,18 @@ int ymx_decode_filter(const void *const *head /* host array of device ptrs */, i
                       int *src_idx, int *counts, int cap, void *workspace, size_t ws_bytes,
                       void *stream);
 
+/* ymx_decode_filter on conv maps whose grid cells are padded: cell (row, col) of head s
+ * starts cell_ld[s] elements after the previous one (cell_ld[s] >= 3*(5+C), host array);
+ * the 3*(5+C) values of a cell are dense, the rest of the stride is ignored.  The same
+ * reference functions (utils.py:107-131, 142-167); lets the producing convolution write
+ * 16-byte aligned rows (e.g. 256 for the 255 channels of 80 classes). */
+int ymx_decode_filter_strided(const void *const *head, const int *cell_ld /* host */, int n_scales,
+                              const int *S /* host */, int B, int C, int head_dtype,
+                              const float *anchors, const float *strides, const float *xyscale,
+                              int filter, float thr, float image_size, float *boxes, float *scores,
+                              int *src_idx, int *counts, int cap, void *workspace, size_t ws_bytes,
+                              void *stream);
+
 /* decode (utils.py:107-126) with objectness and class probability kept apart, as
  * decode and decode_train (utils.py:128-131) return them: boxes [B,cap,4] xywh
  * pixels, conf [B,cap] = sigmoid(t_conf), prob class-major [B,C,cap] = sigmoid(t_c). */

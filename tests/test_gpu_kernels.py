@@ -344,6 +344,59 @@ def test_fused_decode_filter_416_edges():
             assert counts.tolist() == [0] * B
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decode_filter_strided_cells(dtype):
+    """ymx_decode_filter_strided on maps with padded grid cells (garbage in the padding) gives
+    exactly what ymx_decode_filter gives on the dense maps, filtered and unfiltered."""
+    import ctypes
+    from yolo_amd import _lib, utils as U
+    gen = torch.Generator().manual_seed(21)
+    C, B = 80, 2
+    sides, pads = (52, 26, 13), (1, 9, 0)                  # cell strides 256, 264, 255
+    dense = [(torch.randn(B, S, S, 3 * (5 + C), generator=gen) * 2).to(DEV).to(dtype) for S in sides]
+    padded = []
+    for h, pad in zip(dense, pads):
+        t = torch.full(h.shape[:3] + (h.shape[3] + pad,), float("nan"), device=DEV, dtype=dtype)
+        t[..., :h.shape[3]] = h
+        padded.append(t)
+    anc = U.default_anchors()
+    strides, xys = [8, 16, 32], [1.2, 1.1, 1.05]
+    L = _lib.lib()
+    for filt, thr in ((0, 0.0), (1, 0.25), (1, -1.0)):
+        outs = []
+        for maps, strided in ((dense, False), (padded, True)):
+            sc = U._Scales(maps, strides, xys, anc, cell_ld=[m.shape[-1] for m in maps] if strided else None)
+            cap = U._round4(sc.N)
+            boxes = torch.zeros((B, cap, 4), device=DEV)
+            scores = torch.zeros((B, C, cap), device=DEV)
+            src = torch.zeros((B, cap), device=DEV, dtype=torch.int32)
+            counts = torch.zeros((B,), device=DEV, dtype=torch.int32)
+            wsb = L.ymx_decode_workspace_bytes(B, sc.n, sc.S)
+            ws = torch.empty((wsb,), device=DEV, dtype=torch.uint8)
+            tail = (sc.n, sc.S, B, C, _lib.dtype_code(dtype), sc.anchors, sc.strides, sc.xyscale, filt, thr, 416.0,
+                    _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(src), _lib.ptr(counts), cap, _lib.ptr(ws), wsb, _lib.stream())
+            if strided:
+                _lib.check(L.ymx_decode_filter_strided(sc.ptrs, sc.cell_ld, *tail))
+            else:
+                _lib.check(L.ymx_decode_filter(sc.ptrs, *tail))
+            n = counts.cpu().numpy()
+            outs.append((n, [boxes[b, :n[b]].cpu().numpy() for b in range(B)],
+                         [scores[b, :, :n[b]].cpu().numpy() for b in range(B)],
+                         [src[b, :n[b]].cpu().numpy() for b in range(B)] if filt else None))
+        (n0, b0, s0, i0), (n1, b1, s1, i1) = outs
+        np.testing.assert_array_equal(n0, n1)
+        for b in range(B):
+            np.testing.assert_array_equal(b0[b], b1[b])
+            np.testing.assert_array_equal(s0[b], s1[b])
+            if filt:
+                np.testing.assert_array_equal(i0[b], i1[b])
+    # a cell stride below 3*(5+C) is refused
+    bad = (ctypes.c_int * 3)(254, 255, 255)
+    sc = U._Scales(dense, strides, xys, anc)
+    rc = L.ymx_decode_filter_strided(sc.ptrs, bad, *tail)
+    assert rc != 0 and b"cell stride" in L.ymx_last_error()
+
+
 # ----------------------------------------------------------------------------- NMS
 def _gpu_nms(boxes, scores, counts, per_class, total, iou, thr, src=None):
     import yolo_amd as Y

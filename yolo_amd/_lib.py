@@ -40,6 +40,9 @@ SIGNATURES = {
     "ymx_decode_filter": (_i, [ctypes.POINTER(_vp), _i, ctypes.POINTER(_i), _i, _i, _i,
                                ctypes.POINTER(_f), ctypes.POINTER(_f), ctypes.POINTER(_f),
                                _i, _f, _f, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "ymx_decode_filter_strided": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, ctypes.POINTER(_i), _i, _i, _i,
+                               ctypes.POINTER(_f), ctypes.POINTER(_f), ctypes.POINTER(_f),
+                               _i, _f, _f, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "ymx_decode_split": (_i, [ctypes.POINTER(_vp), _i, ctypes.POINTER(_i), _i, _i, _i,
                               ctypes.POINTER(_f), ctypes.POINTER(_f), ctypes.POINTER(_f),
                               _vp, _vp, _vp, _vp, _i, _vp]),

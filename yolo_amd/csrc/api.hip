@@ -13,6 +13,7 @@ namespace ymx {
 
 static thread_local std::string g_err;
 static thread_local float *g_split_conf = nullptr;   // set only inside ymx_decode_split
+static thread_local const int *g_cell_ld = nullptr;  // set only inside ymx_decode_filter_strided
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -291,12 +292,33 @@ int ymx_decode_filter(const void *const *head, int n_scales, const int *S, int B
     a.filter = filter ? 1 : 0; a.thr = thr; a.image_size = image_size;
     a.boxes = boxes; a.scores = scores; a.src_idx = src_idx; a.counts = counts; a.nseg = nseg;
     a.conf = filter ? nullptr : g_split_conf;
+    if (g_cell_ld) {
+        for (int i = 0; i < n_scales; ++i) {
+            const int pad = g_cell_ld[i] - 3 * (5 + C);
+            if (pad < 0) return fail(YMX_EARG, "decode_filter: cell stride %d below 3*(5+C) = %d", g_cell_ld[i], 3 * (5 + C));
+            if (pad > 4096) return fail(YMX_EUNSUPPORTED, "decode_filter: cell stride %d too large", g_cell_ld[i]);
+            a.cell_ld[i] = g_cell_ld[i];
+            if (pad > a.max_pad) a.max_pad = pad;
+        }
+    }
     if (!filter && cap < ncand) return fail(YMX_EARG, "decode_filter: cap %d < %d candidates", cap, ncand);
     if (filter) {
         const int rc = setup_ws(a, workspace, ws_bytes, (hipStream_t)stream);
         if (rc) return rc;
     }
     return launch_decode(a, (hipStream_t)stream);
+}
+
+int ymx_decode_filter_strided(const void *const *head, const int *cell_ld, int n_scales, const int *S, int B, int C,
+                              int head_dtype, const float *anchors, const float *strides, const float *xyscale,
+                              int filter, float thr, float image_size, float *boxes, float *scores, int *src_idx,
+                              int *counts, int cap, void *workspace, size_t ws_bytes, void *stream) {
+    if (!cell_ld) return fail(YMX_EARG, "decode_filter_strided: null cell_ld");
+    g_cell_ld = cell_ld;
+    const int rc = ymx_decode_filter(head, n_scales, S, B, C, head_dtype, anchors, strides, xyscale, filter, thr,
+                                     image_size, boxes, scores, src_idx, counts, cap, workspace, ws_bytes, stream);
+    g_cell_ld = nullptr;
+    return rc;
 }
 
 int ymx_decode_split(const void *const *head, int n_scales, const int *S, int B, int C, int head_dtype,

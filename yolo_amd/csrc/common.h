@@ -202,6 +202,8 @@ struct DecodeArgs {
     int seg_begin[4];            // first segment of each scale (segments of 256 candidates)
     int cand_begin[4];           // first candidate of each scale in the concatenated list
     float stride[3], xyscale[3], anchor[3][3][2];
+    int cell_ld[3];              // elements from one grid cell to the next (>= 3*(5+C)); 0 = dense
+    int max_pad;                 // largest cell_ld - 3*(5+C) over the scales (sizes the staging buffer)
     int n_scales, B, C, N, cap, head_dtype;
     int filter;                  // 0: decode only, 1: decode+filter, 2: filter decoded input
     float thr, image_size;

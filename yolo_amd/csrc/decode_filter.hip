@@ -63,7 +63,7 @@ decode_kernel(const DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int D = 5 + a.C;
     float *stage = (float *)smem_raw;                       // [64*D] (MODE 0/1)
-    const int stage_words = (MODE == 2) ? 0 : ((64 * D + 3) & ~3);
+    const int stage_words = (MODE == 2) ? 0 : ((64 * D + 22 * a.max_pad + 3) & ~3);
     float *smax = stage + stage_words;                      // [2][4][64], by sub-step parity
     int *sint = (int *)(smax + 512);                        // [0] segment, [1] base
 
@@ -105,11 +105,22 @@ decode_kernel(const DecodeArgs a) {
         float m = -INFINITY;
         box[ss] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (MODE != 2) {
-            const HT *src = (const HT *)a.head[sc] + ((size_t)b * Ns + c0) * D;
-            stage_rows<HT>(stage, src, nvalid * D, t);
+            // The 64 candidates' rows: contiguous when the cells are dense (cell_ld = 3*D);
+            // with padded cells the span from the first to the last candidate is staged as
+            // it lies, padding included, and each lane finds its row inside it.
+            const int ld = a.cell_ld[sc] ? a.cell_ld[sc] : 3 * D;
+            const int cell0 = c0 / 3, a0 = c0 - cell0 * 3;
+            const HT *src = (const HT *)a.head[sc] + ((size_t)b * S * S + cell0) * ld + a0 * D;
+            int span = 0;
+            if (nvalid > 0) {
+                const int cl = c0 + nvalid - 1, cellL = cl / 3;
+                span = (cellL - cell0) * ld + (cl - cellL * 3 + 1) * D - a0 * D;
+            }
+            stage_rows<HT>(stage, src, span, t);
             __syncthreads();
             if (live) {
-                const float *row = stage + lane * D;
+                const int cme = c0 + lane, cellm = cme / 3;
+                const float *row = stage + (cellm - cell0) * ld + (cme - cellm * 3) * D - a0 * D;
                 const float conf = sigmoid_f(row[4]);
                 const float cmul = (MODE == 0 && a.conf) ? 1.0f : conf;
 #pragma unroll
@@ -228,7 +239,7 @@ decode_kernel(const DecodeArgs a) {
 template <typename HT, int CPT>
 static int launch_mode(const DecodeArgs &a, hipStream_t s) {
     const int D = 5 + a.C;
-    const size_t stage_words = (a.filter == 2) ? 0 : ((64 * (size_t)D + 3) & ~(size_t)3);
+    const size_t stage_words = (a.filter == 2) ? 0 : ((64 * (size_t)D + 22 * (size_t)a.max_pad + 3) & ~(size_t)3);
     const size_t lds = (stage_words + 512 + 4) * 4;
     if (lds > 64 * 1024) return fail(YMX_EUNSUPPORTED, "decode: %d classes need %zu bytes of LDS", a.C, lds);
     dim3 grid(a.nseg, a.B), block(256);

@@ -111,14 +111,27 @@ class Detector(nn.Module):
             keep.append(t)
             return t
 
-        def conv(layer, x, h, w, residual=None, x_code=code, out_dtype=cdt):
+        def conv(layer, x, h, w, residual=None, x_code=code, out_dtype=cdt, pad_out=False):
             wp, scale, shift, _src = layer.packed(cdt)
-            keep.extend([wp, scale, shift])
             oh, ow = layer.output_hw(h, w)
-            y = buf(oh, ow, layer.filters, out_dtype)
+            cout = layer.filters
+            if pad_out and cout % 8:
+                # Output maps whose channel count is not a multiple of 8 (255 for 80 classes)
+                # are computed as the next multiple: the packed weights already hold zero rows
+                # up to a multiple of 128, scale/shift get zeros, so the extra channels are
+                # exact zeros.  Rows are then 16-byte aligned and the convolution takes its
+                # vector store path; the caller sees the first `filters` channels as a view.
+                cout = (cout + 7) // 8 * 8
+                extra = cout - layer.filters
+                if scale is not None:
+                    scale = torch.cat([scale, scale.new_zeros(extra)])
+                if shift is not None:
+                    shift = torch.cat([shift, shift.new_zeros(extra)])
+            keep.extend([wp, scale, shift])
+            y = buf(oh, ow, cout, out_dtype)
             o = _lib.ymx_op()
             o.kind = 1
-            o.B, o.H, o.W, o.Cin, o.Cout = B, h, w, layer.in_channels, layer.filters
+            o.B, o.H, o.W, o.Cin, o.Cout = B, h, w, layer.in_channels, cout
             o.k, o.stride, o.act = layer.kernel_size, 2 if layer.downsample else 1, layer.act_code
             o.dtype, o.x_dtype, o.out_dtype = code, x_code, _lib.dtype_code(out_dtype)
             o.x_ld = o.res_ld = o.y_ld = 0
@@ -160,27 +173,28 @@ class Detector(nn.Module):
         s3, h3, w3 = run_stack(bb.layer_stack_3, s2, h2, w2)
         x, _, _ = run_stack(hd.layer_stack_1, s3, h3, w3)
         l, _, _ = conv(hd.lbbox_layer_stack[0], x, h3, w3)
-        l, _, _ = conv(hd.lbbox_layer_stack[1], l, h3, w3, out_dtype=hd.out_dtype)
+        l, _, _ = conv(hd.lbbox_layer_stack[1], l, h3, w3, out_dtype=hd.out_dtype, pad_out=True)
         x = upcat(s2, x, h3, w3, s2.shape[-1], x.shape[-1])
         x, _, _ = run_stack(hd.layer_stack_2, x, h2, w2)
         m, _, _ = conv(hd.mbbox_layer_stack[0], x, h2, w2)
-        m, _, _ = conv(hd.mbbox_layer_stack[1], m, h2, w2, out_dtype=hd.out_dtype)
+        m, _, _ = conv(hd.mbbox_layer_stack[1], m, h2, w2, out_dtype=hd.out_dtype, pad_out=True)
         s = upcat(s1, x, h2, w2, s1.shape[-1], x.shape[-1])
         s, _, _ = run_stack(list(hd.sbbox_layer_stack)[:-1], s, h1, w1)
-        s, _, _ = conv(hd.sbbox_layer_stack[-1], s, h1, w1, out_dtype=hd.out_dtype)
+        s, _, _ = conv(hd.sbbox_layer_stack[-1], s, h1, w1, out_dtype=hd.out_dtype, pad_out=True)
 
         plan = _Plan()
         plan.ops = (_lib.ymx_op * len(ops))(*ops)
         plan.n_ops = len(ops)
         plan.keep = keep
-        plan.heads = (s, m, l)
+        C = self.num_classes
+        padded = (s, m, l)                                  # [B,S,S,cell_ld] buffers the convs write
+        plan.heads = tuple(t[..., :3 * (5 + C)] for t in padded)    # what callers see: [B,S,S,3*(5+C)]
+        plan.head_dtype = s.dtype
         plan.first_is_direct = True
         # post-processing buffers
-        C = self.num_classes
-        heads5 = [t.view(B, t.shape[1], t.shape[2], 3, 5 + C) for t in plan.heads]
         anc = _utils.default_anchors()
-        plan.scales = _utils._Scales(heads5, _YOLO["strides"], _YOLO["xyscale"], anc)
-        plan.heads5 = heads5
+        plan.scales = _utils._Scales(padded, _YOLO["strides"], _YOLO["xyscale"], anc,
+                                     cell_ld=[t.shape[-1] for t in padded])
         cap = _utils._round4(plan.scales.N)
         plan.cap = cap
         f32, i32 = torch.float32, torch.int32
@@ -225,11 +239,11 @@ class Detector(nn.Module):
         L = _lib.lib()
         sc = plan.scales
         B, C = plan.boxes.shape[0], self.num_classes
-        _lib.check(L.ymx_decode_filter(sc.ptrs, sc.n, sc.S, B, C, _lib.dtype_code(plan.heads5[0].dtype), sc.anchors,
-                                       sc.strides, sc.xyscale, 1, float(self.score_threshold), float(image_size),
-                                       _lib.ptr(plan.boxes), _lib.ptr(plan.scores_cm), _lib.ptr(plan.src_idx),
-                                       _lib.ptr(plan.counts), plan.cap, _lib.ptr(plan.dec_ws), plan.dec_ws_bytes,
-                                       _lib.stream()))
+        _lib.check(L.ymx_decode_filter_strided(sc.ptrs, sc.cell_ld, sc.n, sc.S, B, C, _lib.dtype_code(plan.head_dtype),
+                                               sc.anchors, sc.strides, sc.xyscale, 1, float(self.score_threshold),
+                                               float(image_size), _lib.ptr(plan.boxes), _lib.ptr(plan.scores_cm),
+                                               _lib.ptr(plan.src_idx), _lib.ptr(plan.counts), plan.cap,
+                                               _lib.ptr(plan.dec_ws), plan.dec_ws_bytes, _lib.stream()))
         _lib.check(L.ymx_nms_combined(_lib.ptr(plan.boxes), _lib.ptr(plan.scores_cm), _lib.ptr(plan.counts),
                                       _lib.ptr(plan.src_idx), B, plan.cap, C, int(self.max_outputs_per_class),
                                       int(self.max_outputs), float(self.iou_threshold), float(self.score_threshold),

@@ -54,9 +54,12 @@ def _round4(n):
 class _Scales(object):
     """Host-side argument block of the decode entry points."""
 
-    def __init__(self, heads, strides, xyscale, anchors):
+    def __init__(self, heads, strides, xyscale, anchors, cell_ld=None):
         n = len(heads)
         self.n = n
+        # cell_ld: elements from one grid cell to the next when the maps are padded views
+        # (then ymx_decode_filter_strided is the entry point to call), else None
+        self.cell_ld = None if cell_ld is None else (ctypes.c_int * n)(*[int(v) for v in cell_ld])
         self.ptrs = (ctypes.c_void_p * n)(*[h.data_ptr() for h in heads])
         self.S = (ctypes.c_int * n)(*[int(h.shape[1]) for h in heads])
         self.strides = (ctypes.c_float * n)(*[float(s) for s in strides])
