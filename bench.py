@@ -12,9 +12,11 @@ rank runs its own 64 images (weak scaling) and the step ends with the all-gather
 detection records.  Rank 0 prints ONE JSON line.
 
 Besides the headline value the line carries
-  roofline      the dominant kernel (the 128x128-tile bf16 implicit-GEMM convolution):
-                algorithmic FLOPs of its launches / their summed duration, measured with
-                events between the launches of a step, against the dense bf16 MFMA peak;
+  roofline      the kernel with the most time per step (the resident-slab 3x3 bf16
+                implicit-GEMM convolution): algorithmic FLOPs of its launches / their summed
+                duration, measured with events between the launches of a step, against the
+                dense bf16 MFMA peak; `traffic` = HBM bytes per launch of that kernel from
+                the committed rocprofv3 --pmc passes (profiles/), null if there are none;
   cpu_baseline  the CPU oracle (torch-CPU fp32 convs + C post-processing) timed on this
                 host on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -53,6 +55,27 @@ def conv_kernel_name(op):
         return "conv_igemm_dma2_bf16_%dx256" % tq     # narrow-layer LDS-DMA kernel, several workgroups per CU
     tile = "256x32" if op.Cout <= 32 else ("256x64" if op.Cout <= 64 else "128x128")
     return "conv_igemm_%s_%s" % ("bf16" if bf16 else "f32", tile)
+
+
+# bench label -> device kernel name in the rocprofv3 summaries under profiles/
+PMC_KERNEL = {
+    "conv_igemm_halo_bf16_256x256": "conv_igemm_halo_kernel<bf16>",
+    "conv_igemm_dma_bf16_256x256": "conv_igemm_dma_kernel<bf16, 256>",
+}
+
+
+def pmc_traffic(label):
+    """HBM bytes per launch of the labelled kernel, from the newest committed --pmc summary."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files or label not in PMC_KERNEL:
+        return None
+    try:
+        with open(files[-1]) as f:
+            k = json.load(f)["kernels"].get(PMC_KERNEL[label])
+        return None if k is None else round(k["hbm_bytes_per_launch"], 1)
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def conv_flops(op):
@@ -222,7 +245,7 @@ def main():
         conv_ms = sum(v["ms"] for v in groups.values())
         conv_flops_total = sum(v["flops"] for v in groups.values())
         line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                            "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                            "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(name),
                             "launches_per_step": g["launches"], "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                             "flops_per_step": g["flops"]}
         post_ms, plan = time_postproc(det, x, max(3, min(args.steps, 10)))
