@@ -45,8 +45,11 @@ const char *ymx_last_error(void);
  * fewest 256x256 output tiles for which a bf16 convolution with more than 128 output
  * channels runs on the large-tile LDS-DMA kernel instead of the 128x128 kernel
  * (default 160; 0 forces it, a huge value disables it).  "dma_variant": which large-tile
- * kernel wide layers use (1: 256x256 tile, one workgroup per CU, the default; 2: 256x128
- * tile, two per CU).  "dma_narrow": 1 (default) runs bf16 layers of <= 128 output
+ * kernel wide layers use (5, the default: chosen per shape -- input pixels resident in
+ * LDS for 3x3 stride 1, phase-staggered wave groups for long 1x1 layers, the two-stage
+ * kernel otherwise; 1: two-stage 256x256 everywhere; 2: 256x128 tile, two workgroups per
+ * CU; 3: four-stage ring; 4: phase-staggered wave groups everywhere).  "dma_stages":
+ * pipeline depth (3 or 4, default 4) of the 32- and 64-channel narrow-layer tiles.  "dma_narrow": 1 (default) runs bf16 layers of <= 128 output
  * channels with at least dma_min_tiles 256-pixel tiles on the LDS-DMA kernel, 0 on the
  * register-staged kernel.  All kernels add the K terms in the same order: results do
  * not depend on these options. */
@@ -68,8 +71,14 @@ int ymx_set_option(const char *name, long long value);
  * (layers.py:76).
  *
  * w is the PACKED kernel produced by ymx_pack_weights from the reference's HWIO
- * fp32 layout.  dtype is the storage type of x, residual and the MFMA operands
- * (accumulation is always fp32).  scale/shift are fp32 [Cout].
+ * fp32 layout: an opaque buffer of ymx_packed_weight_bytes bytes, valid for this
+ * library version only (rows = output channels padded to 128, columns = K padded to
+ * 64, K ordered in blocks of 64 input channels, then filter taps, then the channels
+ * of the block; Cin not a multiple of 8 keeps HWIO fp32).  dtype is the storage type
+ * of x, residual and the MFMA operands (accumulation is always fp32).  scale/shift
+ * are fp32 [Cout].  All kernels the library may choose for a shape add the K terms
+ * in the same order: results do not depend on the tuning options or on the batch a
+ * pixel is computed in.
  */
 size_t ymx_packed_weight_bytes(int k, int Cin, int Cout, int dtype);
 int ymx_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype,
