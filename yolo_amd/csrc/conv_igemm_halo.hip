@@ -195,8 +195,9 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
     // phase 2), after the issue of phase 3 "W(m0) of the next tile has landed" (read in its
     // phase 0); a slab instruction of K tile j is covered by the wait in phase 3 of tile j+1.
     // Every slot is re-issued two or more phases after its last read.
-    // (Measured: spreading the pixel-fragment reads as (8, 4, 8, 4) per phase by reading the
-    // next tile's first half in phase 3 was 8 % slower than this (12, 4, 8, 0).)
+    // (Measured alternatives, both slower than this (12, 4, 8, 0) LDS reads per phase: reading
+    // the next tile's first pixel half in phase 3, (8, 4, 8, 4), by 8 %; cutting the phases by
+    // K half instead of pixel half, (8, 8, 4, 4), by 2-3 %.)
     int cb = 0, tap = 0;
 #ifdef YMX_EXP_NODMA
 #define issue_w(...) ((void)0)
