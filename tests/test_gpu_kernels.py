@@ -132,6 +132,41 @@ def test_conv_plain_entry_point_and_strides():
     assert torch.equal(yw[..., 8:40], y) and bool((yw[..., :8] == 7).all()) and bool((yw[..., 40:] == 7).all())
 
 
+def test_conv_wide_kernels_with_pixel_strides():
+    """The wide-layer kernels (resident-slab 3x3 and LDS-DMA 1x1) reading an input embedded in a
+    wider buffer, adding a strided shortcut and writing into a slice of a wider output."""
+    from yolo_amd import _lib
+    g = torch.Generator().manual_seed(77)
+    B, H, W, cin, cout = 2, 10, 12, 64, 256
+    L = _lib.lib()
+    try:
+        _lib.check(L.ymx_set_option(b"dma_min_tiles", 0))
+        for k in (3, 1):
+            x = N.bf16_round(torch.randn(B, H, W, cin, generator=g))
+            p = {"kernel": N.bf16_round(torch.randn(k, k, cin, cout, generator=g) * 0.05), "bias": torch.randn(cout, generator=g)}
+            res = N.bf16_round(torch.randn(B, H, W, cout, generator=g))
+            want = (N.yolo_conv(x, p, False, "mish") + res).numpy()
+            layer = make_conv(p, k, False, "mish", False, torch.bfloat16)
+            wp, scale, shift, _ = layer.packed(torch.bfloat16)
+            xd, rd = x.to(DEV).bfloat16(), res.to(DEV).bfloat16()
+            y = torch.empty((B, H, W, cout), device=DEV, dtype=torch.bfloat16)
+            _lib.check(L.ymx_conv2d_fused(_lib.ptr(xd), _lib.ptr(wp), None, _lib.ptr(shift), _lib.ptr(rd), _lib.ptr(y), B, H, W,
+                                          cin, cout, k, 1, _lib.ACT_MISH, _lib.BF16, _lib.stream()))
+            assert rel_err(y.float().cpu().numpy(), want) < 1e-2
+            xw = torch.full((B, H, W, 96), 3.0, device=DEV, dtype=torch.bfloat16)
+            xw[..., 8:72] = xd
+            rw = torch.full((B, H, W, 264), -2.0, device=DEV, dtype=torch.bfloat16)
+            rw[..., :cout] = rd
+            yw = torch.full((B, H, W, 320), 7.0, device=DEV, dtype=torch.bfloat16)
+            _lib.check(L.ymx_conv2d_fused_ex(xw[..., 8:].data_ptr(), _lib.ptr(wp), None, _lib.ptr(shift), _lib.ptr(rw),
+                                             yw[..., 32:].data_ptr(), B, H, W, cin, cout, k, 1, _lib.ACT_MISH, _lib.BF16,
+                                             _lib.BF16, _lib.BF16, 96, 264, 320, _lib.stream()))
+            assert torch.equal(yw[..., 32:288], y), k
+            assert bool((yw[..., :32] == 7).all()) and bool((yw[..., 288:] == 7).all()), k
+    finally:
+        _lib.check(L.ymx_set_option(b"dma_min_tiles", 160))
+
+
 DMA_SHAPES = [
     # B, H, W, Cin, Cout, k, down, act, residual     (all routed to the large-tile LDS-DMA kernel)
     (2, 13, 13, 64, 255, 1, False, None, False),        # one partial channel tile, ragged pixels
