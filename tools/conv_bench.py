@@ -13,6 +13,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolo_amd import _lib                      # noqa: E402
+
+if os.environ.get("YMX_LIB"):                    # an experimental build of the library
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["YMX_LIB"])
 from yolo_amd.layers import YOLOConv            # noqa: E402
 
 DEFAULT = [

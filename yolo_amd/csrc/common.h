@@ -25,6 +25,20 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
+// 16-byte streaming stores of a layer's output: the non-temporal hint keeps 100s of MB of
+// activations from displacing the weights and the input tiles other workgroups are still
+// re-reading in L2 (measured: -1.6 % on the detector step).
+typedef __attribute__((ext_vector_type(4))) unsigned int st_u32x4_t;
+typedef __attribute__((ext_vector_type(4))) float st_f32x4_t;
+__device__ __forceinline__ void store_stream16(void *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const st_u32x4_t v = {a, b, c, d};
+    __builtin_nontemporal_store(v, (st_u32x4_t *)p);
+}
+__device__ __forceinline__ void store_stream16(void *p, float a, float b, float c, float d) {
+    const st_f32x4_t v = {a, b, c, d};
+    __builtin_nontemporal_store(v, (st_f32x4_t *)p);
+}
+
 template <typename T> struct elem;
 template <> struct elem<float> {
     static constexpr int code = YMX_F32;

@@ -159,8 +159,8 @@ conv_first_mfma_kernel(const ConvArgs a, const int nchunk) {
                     v[r] = act_f(affine_f(d0[r], sc[r], sh[r]), a.act);
                     v[4 + r] = act_f(affine_f(d1[r], sc[4 + r], sh[4 + r]), a.act);
                 }
-                *(uint4 *)(y + (size_t)pix[f] * a.y_ld + 8 * g) =
-                    make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+                store_stream16(y + (size_t)pix[f] * a.y_ld + 8 * g, pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]),
+                               pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
             }
         }
     }
@@ -252,8 +252,8 @@ conv_first_rows_kernel(const ConvArgs a, const int chunks_per_row, const int nch
                     v[r] = act_f(affine_f(d0[r], sc[r], sh[r]), a.act);
                     v[4 + r] = act_f(affine_f(d1[r], sc[4 + r], sh[4 + r]), a.act);
                 }
-                *(uint4 *)(y + ((size_t)rowid * a.OW + ow) * a.y_ld + 8 * g) =
-                    make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+                store_stream16(y + ((size_t)rowid * a.OW + ow) * a.y_ld + 8 * g, pack2_bf16(v[0], v[1]),
+                               pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
             }
         }
     }

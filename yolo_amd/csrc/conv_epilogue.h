@@ -145,11 +145,11 @@ __device__ __forceinline__ void epi_run(const ConvArgs &a, f32x4_t (&acc)[NI][NJ
                 if (p < a.P && co < a.Cout) {
                     OT *yp = y + (size_t)p * a.y_ld + co;
                     if constexpr (sizeof(OT) == 2) {
-                        *(uint4 *)yp = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]),
-                                                  pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+                        store_stream16(yp, pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]),
+                                       pack2_bf16(v[6], v[7]));
                     } else {
-                        *(float4 *)yp = make_float4(v[0], v[1], v[2], v[3]);
-                        *(float4 *)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        store_stream16(yp, v[0], v[1], v[2], v[3]);
+                        store_stream16(yp + 4, v[4], v[5], v[6], v[7]);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);

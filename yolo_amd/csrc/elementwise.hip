@@ -63,7 +63,7 @@ upsample2x_concat_kernel(const T *__restrict__ skip, const T *__restrict__ x, T 
                 out = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
             }
         }
-        *(uint4 *)(y + pix * CT + (size_t)ch * KCH) = out;
+        store_stream16(y + pix * CT + (size_t)ch * KCH, out.x, out.y, out.z, out.w);
     }
 }
 
