@@ -180,11 +180,19 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+    # Rehearsal knobs for boxes with fewer GPUs than ranks (not used by the driver): every rank
+    # on one device, gloo instead of RCCL.
+    backend = os.environ.get("YMX_BENCH_BACKEND", "nccl")
+    if os.environ.get("YMX_BENCH_DEVICE") is not None:
+        local = int(os.environ["YMX_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from yolo_amd import Detector
     from yolo_amd import dist as ydist
@@ -218,7 +226,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3

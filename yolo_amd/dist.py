@@ -68,8 +68,13 @@ def all_gather_detections(det, global_batch, group=None):
     if det[1].shape[0] != mine:
         raise ValueError("rank %d holds %d images, its shard is %d" % (rank, det[1].shape[0], mine))
     rec = pack_detections(det, rows)
+    device = rec.device
+    if rec.is_cuda and dist.get_backend(group) != "nccl":
+        rec = rec.cpu()             # gloo gathers host tensors only; RCCL takes the device buffer as is
     out = [torch.empty_like(rec) for _ in range(world)]
     dist.all_gather(out, rec, group=group)
+    if out[0].device != device:
+        out = [o.to(device) for o in out]
     parts = []
     for r in range(world):
         _, cnt = shard_range(global_batch, r, world)
