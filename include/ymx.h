@@ -48,7 +48,7 @@ const char *ymx_last_error(void);
  * kernel wide layers use (5, the default: chosen per shape -- input pixels resident in
  * LDS for 3x3 stride 1, phase-staggered wave groups for long 1x1 layers, the two-stage
  * kernel otherwise; 1: two-stage 256x256 everywhere; 2: 256x128 tile, two workgroups per
- * CU; 3: four-stage ring; 4: phase-staggered wave groups everywhere).  "dma_stages":
+ * CU; 4: phase-staggered wave groups everywhere).  "dma_stages":
  * pipeline depth (3 or 4, default 4) of the 32- and 64-channel narrow-layer tiles.  "dma_narrow": 1 (default) runs bf16 layers of <= 128 output
  * channels with at least dma_min_tiles 256-pixel tiles on the LDS-DMA kernel, 0 on the
  * register-staged kernel.  All kernels add the K terms in the same order: results do

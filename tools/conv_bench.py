@@ -50,8 +50,8 @@ def main():
         res = torch.randn(B, oh, ow, cout, generator=g).cuda().bfloat16()
         flops = 2.0 * B * oh * ow * k * k * cin * cout
         line = "B%d %dx%d %4d->%4d k%d s%d :" % (B, H, W, cin, cout, k, stride)
-        for kern, tiles, variant in (("128", 1 << 40, 1), ("dma1", 0, 1), ("dma2", 0, 2), ("dma2s4", 0, 2), ("dma3", 0, 3), ("dma4", 0, 4), ("dma5", 0, 5)):
-            if kern in ("dma3", "dma4", "dma5") and cout <= 128:
+        for kern, tiles, variant in (("128", 1 << 40, 1), ("dma1", 0, 1), ("dma2", 0, 2), ("dma2s4", 0, 2), ("dma4", 0, 4), ("dma5", 0, 5)):
+            if kern in ("dma4", "dma5") and cout <= 128:
                 continue
             if kern == "dma2s4" and cout > 64:
                 continue

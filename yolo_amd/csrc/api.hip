@@ -112,7 +112,6 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
                 switch (g_dma_variant) {
                 case 1: return launch_conv_igemm_dma(a, s);
                 case 2: return launch_conv_igemm_dma2(a, s);
-                case 3: return launch_conv_igemm_dma3(a, s);
                 case 4: return launch_conv_igemm_dma4(a, s);
                 default:
                     // 3x3 stride 1: input pixels resident in LDS across the taps; long 1x1
@@ -157,7 +156,7 @@ int ymx_set_option(const char *name, long long value) {
         return YMX_OK;
     }
     if (!strcmp(name, "dma_variant")) {
-        if (value < 1 || value > 5) return fail(YMX_EARG, "set_option: dma_variant must be 1..5");
+        if (value < 1 || value > 5 || value == 3) return fail(YMX_EARG, "set_option: dma_variant must be 1, 2, 4 or 5");
         g_dma_variant = value;
         return YMX_OK;
     }

@@ -195,7 +195,6 @@ static inline int packed_rows(int Cout) { return ((Cout + 127) / 128) * 128; }
 int launch_conv_igemm(const ConvArgs &a, hipStream_t s);
 int launch_conv_igemm_dma(const ConvArgs &a, hipStream_t s);
 int launch_conv_igemm_dma2(const ConvArgs &a, hipStream_t s);
-int launch_conv_igemm_dma3(const ConvArgs &a, hipStream_t s);
 int launch_conv_igemm_dma4(const ConvArgs &a, hipStream_t s);
 int launch_conv_igemm_halo(const ConvArgs &a, hipStream_t s);
 bool conv_halo_eligible(const ConvArgs &a);
