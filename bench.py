@@ -41,7 +41,7 @@ def conv_kernel_name(op):
         return "upsample2x_concat"
     bf16 = op.dtype == 1
     if (op.Cin % 8 if bf16 else op.Cin % 4):
-        return "conv_direct"
+        return "conv_first_rows" if (op.Cin == 3 and op.k == 3 and op.stride == 1 and op.Cout == 32) else "conv_direct"
     # mirrors the choice in yolo_amd/csrc/api.hip (default options)
     oh = op.H if op.stride == 1 else (op.H + 1 - op.k) // 2 + 1
     ow = op.W if op.stride == 1 else (op.W + 1 - op.k) // 2 + 1
@@ -49,7 +49,9 @@ def conv_kernel_name(op):
     if bf16 and op.Cout > 128 and ptiles * ((op.Cout + 255) // 256) >= 160:
         if op.k == 3 and op.stride == 1 and op.Cin % 64 == 0 and op.W <= 59:
             return "conv_igemm_halo_bf16_256x256"     # 3x3: input pixels resident in LDS across the taps
-        return "conv_igemm_dma_bf16_256x256"          # large-tile LDS-DMA kernel
+        if op.k == 1 and ptiles * ((op.Cout + 255) // 256) >= 600:
+            return "conv_igemm_dma4_bf16_256x256"     # long 1x1 layers: phase-staggered wave groups
+        return "conv_igemm_dma_bf16_256x256"          # two-stage large-tile LDS-DMA kernel
     if bf16 and op.Cout <= 128 and ptiles >= 160:
         tq = 32 if op.Cout <= 32 else (64 if op.Cout <= 64 else 128)
         return "conv_igemm_dma2_bf16_%dx256" % tq     # narrow-layer LDS-DMA kernel, several workgroups per CU
@@ -61,6 +63,7 @@ def conv_kernel_name(op):
 PMC_KERNEL = {
     "conv_igemm_halo_bf16_256x256": "conv_igemm_halo_kernel<bf16>",
     "conv_igemm_dma_bf16_256x256": "conv_igemm_dma_kernel<bf16, 256>",
+    "conv_igemm_dma4_bf16_256x256": "conv_igemm_dma4_kernel<bf16>",
 }
 
 
