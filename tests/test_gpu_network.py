@@ -157,6 +157,27 @@ def test_full_size_determinism_and_batch_invariance():
             assert torch.equal(u[i:i + 1], v)
 
 
+def test_608_geometry_batch_invariance():
+    """608x608 (grids 76/38/19: the widest rows go to the kernels without a resident slab):
+    finite outputs, and batch 3 equals three runs of batch 1 bit for bit."""
+    from yolo_amd import Detector
+    C = 80
+    det = Detector(num_classes=C, dtype=torch.bfloat16, seed=3).to(DEV)
+    x = _image(3, 608).to(DEV)
+    det.calibrate_(x[:2].contiguous())
+    out = det(x)
+    full = [t.clone() for t in out] + [out.keep_idx.clone()]
+    heads = [h.clone() for h in det.forward_heads(x)]
+    assert [tuple(h.shape) for h in heads] == [(3, 76, 76, 255), (3, 38, 38, 255), (3, 19, 19, 255)]
+    assert all(bool(torch.isfinite(h).all()) for h in heads)
+    assert int(full[3].min()) > 0
+    for i in range(3):
+        one = det(x[i:i + 1].contiguous())
+        one = [t.clone() for t in one] + [one.keep_idx.clone()]
+        for u, v in zip(full, one):
+            assert torch.equal(u[i:i + 1], v)
+
+
 def test_stress_geometry_scaled():
     """NMS stress geometry (1280^2-equivalent heads, 100 800 candidates, 80 classes,
     threshold 0.001) at batch 2: decode+filter+NMS vs the C oracle on the GPU's decode."""
