@@ -178,6 +178,8 @@ DMA_SHAPES = [
     (3, 13, 13, 128, 256, 3, False, "mish", True),       # 3x3 stride 1, whole 64-channel blocks: the resident-slab kernel
     (2, 26, 52, 64, 512, 3, False, "leaky", False),      # one channel block, W = 52, two channel tiles
     (1, 7, 59, 192, 136, 3, False, None, True),          # widest supported row, partial channel tile
+    (40, 3, 2, 64, 256, 3, False, "mish", True),         # tiny images: most taps fall outside, one partial tile
+    (70, 5, 1, 128, 256, 3, False, "leaky", False),      # one-pixel rows, tiles span dozens of images
     # narrow layers: the several-workgroups-per-CU kernel with 128/64/32-channel tiles
     (2, 24, 20, 64, 128, 3, False, "mish", True),
     (1, 31, 33, 32, 64, 3, True, "mish", False),         # stride 2, one tap per K step
