@@ -169,13 +169,17 @@ conv_first_mfma_kernel(const ConvArgs a, const int nchunk) {
 // Same layer, fp32 image, one wave per 64-pixel run of one output row.  All pixel index
 // arithmetic is per wave (no per-lane division).  The K axis is re-ordered so that every
 // lane's operand is one contiguous run of the image: k-group g = tap row g holds the first
-// 8 of that row's 9 values (3 pixels x 3 channels), loaded as two 16-byte buffer loads
-// (out-of-range offsets return zeros); the 9th value of each row goes to a second MFMA
-// (slot 0 of group g).  Weights are permuted to match when the A fragments are built.
-template <int DUMMY>
+// 8 of that row's 9 values (3 pixels x 3 channels), read as three 12-byte buffer loads
+// (12-byte pixels are only dword aligned; out-of-range offsets return zeros); the 9th
+// value of each row goes to a second MFMA (slot 0 of group g).  Weights are permuted to
+// match when the A fragments are built.  The loads of a wave's next run are issued before
+// the arithmetic of the current one (the layer is HBM-bound: 0.13 GB in, 0.71 GB out per
+// 64 images), and the activation is a template parameter so the per-value code is
+// straight-line.
+template <int ACT>
 __global__ void __launch_bounds__(256)
 conv_first_rows_kernel(const ConvArgs a, const int chunks_per_row, const int nchunk) {
-    typedef __attribute__((ext_vector_type(4))) float f4;
+    typedef __attribute__((ext_vector_type(3))) unsigned int u3;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, li = lane & 15;
     const float *__restrict__ w = (const float *)a.w;          // [27][32] fp32 (HWIO)
@@ -200,62 +204,69 @@ conv_first_rows_kernel(const ConvArgs a, const int chunks_per_row, const int nch
     }
     const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
-    for (int chunk = wave_global; chunk < nchunk; chunk += nwaves) {
-        const int rowid = chunk / chunks_per_row;               // b * OH + oh
+
+    // this lane's three pixels (tap row g, columns ow-1 .. ow+1) of each 16-pixel block f
+    auto issue = [&](int chunk, u3 (&p)[4][3]) {
+        const bool live = chunk < nchunk;
+        const int rowid = live ? chunk / chunks_per_row : 0;    // b * OH + oh
         const int ow0 = (chunk - rowid * chunks_per_row) * 64;
         const int b = rowid / a.OH, oh = rowid - b * a.OH;
         const int ih = oh + g - 1;
-        const bool row_ok = g < 3 && (unsigned)ih < (unsigned)a.H;
-        // element offset of (b, ih, ow0 - 1, 0); the image is dense 3-channel fp32
-        const int rowoff = ((b * a.H + ih) * a.W + ow0 - 1) * 3;
-        bf16x8_first_t b1[4], b2[4];
+        const bool row_ok = live && g < 3 && (unsigned)ih < (unsigned)a.H;
+        const int rowoff = ((b * a.H + ih) * a.W + ow0 - 1) * 3;      // (b, ih, ow0 - 1, 0) of the dense fp32 image
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            const int ow = ow0 + f * 16 + li;
             const unsigned off = row_ok ? (unsigned)(rowoff + (f * 16 + li) * 3) * 4u : 0x80000000u;
-            // 12-byte pixels: offsets are only 4-byte aligned, so the run is read as three
-            // 12-byte loads (one per pixel), which need dword alignment only
-            typedef __attribute__((ext_vector_type(3))) unsigned int u3;
-            const u3 p0 = __builtin_amdgcn_raw_buffer_load_b96(xr, off, 0, 0);
-            const u3 p1 = __builtin_amdgcn_raw_buffer_load_b96(xr, off + 12u, 0, 0);
-            const u3 p2 = __builtin_amdgcn_raw_buffer_load_b96(xr, off + 24u, 0, 0);
-            f4 lo, hi;
-            lo[0] = __uint_as_float(p0[0]); lo[1] = __uint_as_float(p0[1]); lo[2] = __uint_as_float(p0[2]);
-            lo[3] = __uint_as_float(p1[0]); hi[0] = __uint_as_float(p1[1]); hi[1] = __uint_as_float(p1[2]);
-            hi[2] = __uint_as_float(p2[0]); hi[3] = __uint_as_float(p2[1]);
-            const float last = __uint_as_float(p2[2]);
-            const bool l_ok = ow >= 1, r_ok = ow + 1 < a.W;
-            b1[f][0] = (__bf16)(l_ok ? lo[0] : 0.0f);
-            b1[f][1] = (__bf16)(l_ok ? lo[1] : 0.0f);
-            b1[f][2] = (__bf16)(l_ok ? lo[2] : 0.0f);
-            b1[f][3] = (__bf16)lo[3];
-            b1[f][4] = (__bf16)hi[0];
-            b1[f][5] = (__bf16)hi[1];
-            b1[f][6] = (__bf16)(r_ok ? hi[2] : 0.0f);
-            b1[f][7] = (__bf16)(r_ok ? hi[3] : 0.0f);
-#pragma unroll
-            for (int j = 1; j < 8; ++j) b2[f][j] = (__bf16)0.0f;
-            b2[f][0] = (__bf16)(r_ok ? last : 0.0f);
+            p[f][0] = __builtin_amdgcn_raw_buffer_load_b96(xr, off, 0, 0);
+            p[f][1] = __builtin_amdgcn_raw_buffer_load_b96(xr, off + 12u, 0, 0);
+            p[f][2] = __builtin_amdgcn_raw_buffer_load_b96(xr, off + 24u, 0, 0);
         }
+    };
+    auto compute = [&](int chunk, const u3 (&p)[4][3]) {
+        const int rowid = chunk / chunks_per_row;
+        const int ow0 = (chunk - rowid * chunks_per_row) * 64;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             const int ow = ow0 + f * 16 + li;
+            const bool l_ok = ow >= 1, r_ok = ow + 1 < a.W;
+            bf16x8_first_t b1, b2;
+            b1[0] = (__bf16)(l_ok ? __uint_as_float(p[f][0][0]) : 0.0f);
+            b1[1] = (__bf16)(l_ok ? __uint_as_float(p[f][0][1]) : 0.0f);
+            b1[2] = (__bf16)(l_ok ? __uint_as_float(p[f][0][2]) : 0.0f);
+            b1[3] = (__bf16)__uint_as_float(p[f][1][0]);
+            b1[4] = (__bf16)__uint_as_float(p[f][1][1]);
+            b1[5] = (__bf16)__uint_as_float(p[f][1][2]);
+            b1[6] = (__bf16)(r_ok ? __uint_as_float(p[f][2][0]) : 0.0f);
+            b1[7] = (__bf16)(r_ok ? __uint_as_float(p[f][2][1]) : 0.0f);
+#pragma unroll
+            for (int j = 1; j < 8; ++j) b2[j] = (__bf16)0.0f;
+            b2[0] = (__bf16)(r_ok ? __uint_as_float(p[f][2][2]) : 0.0f);
             f32x4_first_t d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0], b1[f], d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[1], b1[f], d1, 0, 0, 0);
-            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0], b2[f], d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1], b2[f], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0], b1, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[1], b1, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0], b2, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1], b2, d1, 0, 0, 0);
             if (ow < a.OW) {
                 float v[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = act_f(affine_f(d0[r], sc[r], sh[r]), a.act);
-                    v[4 + r] = act_f(affine_f(d1[r], sc[4 + r], sh[4 + r]), a.act);
+                    v[r] = act_c<ACT>(affine_f(d0[r], sc[r], sh[r]));
+                    v[4 + r] = act_c<ACT>(affine_f(d1[r], sc[4 + r], sh[4 + r]));
                 }
                 store_stream16(y + ((size_t)rowid * a.OW + ow) * a.y_ld + 8 * g, pack2_bf16(v[0], v[1]),
                                pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
             }
         }
+    };
+
+    u3 pa[4][3], pb[4][3];
+    issue(wave_global, pa);
+    for (int chunk = wave_global; chunk < nchunk; chunk += 2 * nwaves) {
+        issue(chunk + nwaves, pb);
+        compute(chunk, pa);
+        if (chunk + nwaves >= nchunk) break;
+        issue(chunk + 2 * nwaves, pa);
+        compute(chunk + nwaves, pb);
     }
 }
 
@@ -269,7 +280,12 @@ int launch_conv_direct(const ConvArgs &a, hipStream_t s) {
         const int cpr = (a.OW + 63) / 64;
         const int nchunk = a.B * a.OH * cpr;
         const int blocks = (nchunk + 3) / 4 < 256 * 8 ? (nchunk + 3) / 4 : 256 * 8;
-        hipLaunchKernelGGL((conv_first_rows_kernel<0>), dim3(blocks), dim3(256), 0, s, a, cpr, nchunk);
+        if (a.act == YMX_ACT_MISH)
+            hipLaunchKernelGGL((conv_first_rows_kernel<YMX_ACT_MISH>), dim3(blocks), dim3(256), 0, s, a, cpr, nchunk);
+        else if (a.act == YMX_ACT_LEAKY)
+            hipLaunchKernelGGL((conv_first_rows_kernel<YMX_ACT_LEAKY>), dim3(blocks), dim3(256), 0, s, a, cpr, nchunk);
+        else
+            hipLaunchKernelGGL((conv_first_rows_kernel<YMX_ACT_NONE>), dim3(blocks), dim3(256), 0, s, a, cpr, nchunk);
         return check_launch("conv_first_rows");
     }
     if (first_layer_shape(a)) {
