@@ -75,6 +75,33 @@ __device__ __forceinline__ bool iou_gt(float ay1, float ax1, float ay2, float ax
     return (inter / uni) > thr;
 }
 
+// Suffix scan of a 1024-bin histogram by 256 threads: returns (through *s_cutbin, which
+// must be 0 on entry, and after a barrier) the highest bin b such that bins b.. hold at
+// least `target` entries, or leaves 0 if all bins together hold fewer.
+__device__ __forceinline__ void hist_cut(const int *hist, int target, int t, int *s_wsum, int *s_cutbin) {
+    const int lane = t & 63;
+    int h[4], local = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h[e] = hist[NMS_BINS - 1 - (4 * t + e)]; local += h[e]; }
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_wsum[t >> 6] = incl;
+    __syncthreads();
+    int run = incl - local;
+    for (int w = 0; w < (t >> 6); ++w) run += s_wsum[w];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool was_below = run < target;
+        run += h[e];
+        if (was_below && run >= target) *s_cutbin = NMS_BINS - 1 - (4 * t + e);
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(256)
 nms_class_kernel(const NmsArgs a) {
     __shared__ u64 buf[NMS_BUF];
@@ -132,31 +159,7 @@ nms_class_kernel(const NmsArgs a) {
             }
         }
         __syncthreads();
-        {
-            // thread t owns bins NMS_BINS-1-4t .. NMS_BINS-4-4t (descending); inclusive scan from the top
-            int h[4], local = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { h[e] = hist[NMS_BINS - 1 - (4 * t + e)]; local += h[e]; }
-            int incl = local;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int up = __shfl_up(incl, d);
-                if (lane >= d) incl += up;
-            }
-            if (lane == 63) s_wsum[t >> 6] = incl;
-            __syncthreads();
-            int before = incl - local;
-            for (int w = 0; w < (t >> 6); ++w) before += s_wsum[w];
-            // the first bin (from the top) at which the running count reaches the target
-            int run = before;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool was_below = run < target;
-                run += h[e];
-                if (was_below && run >= target) s_cutbin = NMS_BINS - 1 - (4 * t + e);
-            }
-            __syncthreads();
-        }
+        hist_cut(hist, target, t, s_wsum, &s_cutbin);
         const int cutbin = s_cutbin;   // 0: fewer than `target` candidates in all, take everything
         u64 floor_key = cutbin > 0 ? (((u64)(ob_thr + ((u32)cutbin << hshift))) << 32) - 1ull : 0ull;   // keys must be > floor_key
         bool cut = cutbin > 0;
@@ -251,14 +254,34 @@ nms_class_kernel(const NmsArgs a) {
     }
 }
 
+// One workgroup per image: the per-class survivors (already in visiting order per class) are
+// merged by (score desc, class asc, index asc).  Only the first `total` are wanted, so the
+// keys are first cut at the highest score-histogram bin edge that leaves at least `total` of
+// them (same histogram as kernel 1), and only those -- a few dozen instead of C * per_class --
+// are sorted.
 __global__ void __launch_bounds__(256)
 nms_merge_kernel(const NmsArgs a, const int npow2) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    u64 *keys = (u64 *)smem_raw;
-    int &s_n = *(int *)(keys + npow2);      // all LDS in the one dynamic array
-    const int b = blockIdx.x, t = threadIdx.x;
+    u64 *keys = (u64 *)smem_raw;                 // [npow2] all keys, then the sorted selection
+    u64 *sel = keys + npow2;                     // [npow2] selection
+    int *hist = (int *)(sel + npow2);            // [NMS_BINS]
+    int *s_misc = hist + NMS_BINS;               // [0..3] wave sums, [4] cut bin, [5] selected, [6] n valid
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63;
     const int PC = a.per_class, nslots = a.C * PC;
-    if (t == 0) s_n = 0;
+    const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const u32 ob_thr = ord_bits(a.score_thr);
+    int hshift = 0;
+    {
+        const u32 range = (a.score_thr < 1.0f) ? ord_bits(1.0f) - ob_thr : (1u << 23);
+        while ((range >> hshift) >= (u32)NMS_BINS) ++hshift;
+    }
+    auto bin_of = [&](u64 key) {
+        const u32 bin = ((u32)(key >> 32) - ob_thr) >> hshift;
+        return bin < (u32)NMS_BINS ? (int)bin : NMS_BINS - 1;
+    };
+    for (int i = t; i < NMS_BINS; i += 256) hist[i] = 0;
+    if (t < 8) s_misc[t] = 0;
+    __syncthreads();
     for (int i = t; i < npow2; i += 256) {
         u64 key = 0;
         if (i < nslots) {
@@ -267,23 +290,42 @@ nms_merge_kernel(const NmsArgs a, const int npow2) {
                 const u64 k1 = a.kept_keys[((size_t)b * a.C + c) * PC + j];
                 const u32 idx = 0xffffffffu - (u32)k1;
                 key = (k1 & 0xffffffff00000000ull) | ((u64)(0x7ffu - (u32)c) << 21) | (u64)(0x1fffffu - idx);
+                atomicAdd(&hist[bin_of(key)], 1);
             }
         }
         keys[i] = key;
     }
     __syncthreads();
-    bitonic_desc(keys, npow2, t);
-    for (int i = t; i < npow2; i += 256)
-        if (keys[i] != 0 && (i + 1 == npow2 || keys[i + 1] == 0)) s_n = i + 1;
+    hist_cut(hist, a.total, t, s_misc, s_misc + 4);
+    const int cutbin = s_misc[4];
+    // order-free compaction of the keys at or above the cut
+    for (int i0 = 0; i0 < npow2; i0 += 256) {
+        const u64 key = keys[i0 + t];
+        const bool pred = key != 0 && bin_of(key) >= cutbin;
+        const u64 bal = __ballot(pred);
+        if (bal) {
+            const int leader = __ffsll((long long)bal) - 1;
+            int pos = 0;
+            if (lane == leader) pos = atomicAdd(&s_misc[5], __popcll(bal));
+            pos = __shfl(pos, leader);
+            if (pred) sel[pos + __popcll(bal & below)] = key;
+        }
+    }
     __syncthreads();
-    const int nvalid = s_n < a.total ? s_n : a.total;
+    const int nsel = s_misc[5];
+    int nsort = 64;
+    while (nsort < nsel) nsort <<= 1;
+    for (int i = nsel + t; i < nsort; i += 256) sel[i] = 0;
+    __syncthreads();
+    bitonic_desc(sel, nsort, t);
+    const int nvalid = nsel < a.total ? nsel : a.total;
     if (t == 0) a.out_valid[b] = nvalid;
     for (int j = t; j < a.total; j += 256) {
         float4 ob = make_float4(0.f, 0.f, 0.f, 0.f);
         float sc = 0.f, cl = 0.f;
         int kidx = -1;
         if (j < nvalid) {
-            const u64 key = keys[j];
+            const u64 key = sel[j];
             const u32 c = 0x7ffu - (u32)((key >> 21) & 0x7ffu);
             const u32 idx = 0x1fffffu - (u32)(key & 0x1fffffu);
             const float4 bx = ((const float4 *)a.boxes)[(size_t)b * a.cap + idx];
@@ -306,7 +348,19 @@ int launch_nms(const NmsArgs &a, hipStream_t s) {
     if (rc) return rc;
     int npow2 = 256;
     while (npow2 < a.C * a.per_class) npow2 <<= 1;
-    hipLaunchKernelGGL(nms_merge_kernel, dim3(a.B), dim3(256), (size_t)npow2 * 8 + 16, s, a, npow2);
+    const size_t merge_lds = (size_t)npow2 * 16 + NMS_BINS * 4 + 32;
+    if (merge_lds > 64 * 1024) {
+        static bool configured = false;
+        if (!configured) {
+            if (hipFuncSetAttribute((const void *)nms_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(YMX_ELAUNCH, "nms_merge: cannot reserve LDS");
+            }
+            configured = true;
+        }
+        if (merge_lds > 160 * 1024) return fail(YMX_EUNSUPPORTED, "nms: C * per_class = %d too large", a.C * a.per_class);
+    }
+    hipLaunchKernelGGL(nms_merge_kernel, dim3(a.B), dim3(256), merge_lds, s, a, npow2);
     return check_launch("nms_merge");
 }
 
