@@ -53,6 +53,9 @@ def conv_kernel_name(op):
             return "conv_igemm_dma4_bf16_256x256"     # long 1x1 layers: phase-staggered wave groups
         return "conv_igemm_dma_bf16_256x256"          # two-stage large-tile LDS-DMA kernel
     if bf16 and op.Cout <= 128 and ptiles >= 160:
+        if op.k == 3 and op.stride == 1 and ((op.Cin == 32 and op.Cout <= 64 and op.W <= 400) or
+                                             (op.Cin == 64 and op.Cout <= 128 and op.W <= 110)):
+            return "conv_igemm_slab2_bf16_cin%d" % op.Cin    # narrow 3x3: input slab resident in LDS
         tq = 32 if op.Cout <= 32 else (64 if op.Cout <= 64 else 128)
         return "conv_igemm_dma2_bf16_%dx256" % tq     # narrow-layer LDS-DMA kernel, several workgroups per CU
     tile = "256x32" if op.Cout <= 32 else ("256x64" if op.Cout <= 64 else "128x128")

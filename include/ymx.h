@@ -49,9 +49,10 @@ const char *ymx_last_error(void);
  * LDS for 3x3 stride 1, phase-staggered wave groups for long 1x1 layers, the two-stage
  * kernel otherwise; 1: two-stage 256x256 everywhere; 2: 256x128 tile, two workgroups per
  * CU; 4: phase-staggered wave groups everywhere).  "dma_stages":
- * pipeline depth (3 or 4, default 4) of the 32- and 64-channel narrow-layer tiles.  "dma_narrow": 1 (default) runs bf16 layers of <= 128 output
- * channels with at least dma_min_tiles 256-pixel tiles on the LDS-DMA kernel, 0 on the
- * register-staged kernel.  All kernels add the K terms in the same order: results do
+ * pipeline depth (3 or 4, default 4) of the 32- and 64-channel narrow-layer tiles.  "dma_narrow": bf16 layers of <= 128 output channels
+ * with at least dma_min_tiles 256-pixel tiles run on the LDS-DMA kernels (2, the default:
+ * with the input-resident kernel for 3x3 stride 1 and 32 or 64 input channels; 1: without
+ * it) or on the register-staged kernel (0).  All kernels add the K terms in the same order: results do
  * not depend on these options. */
 int ymx_set_option(const char *name, long long value);
 

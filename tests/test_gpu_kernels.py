@@ -188,6 +188,9 @@ DMA_SHAPES = [
     (1, 15, 15, 128, 100, 1, False, "leaky", True),      # partial 128 tile
     (1, 17, 9, 16, 24, 3, False, None, False),           # partial 32 tile, Cin 16
     (1, 12, 12, 72, 48, 3, False, "mish", True),         # Cin not a power of two, partial 64 tile
+    (3, 9, 208, 32, 64, 3, False, "mish", True),         # input-slab kernel, rows longer than a tile
+    (5, 11, 104, 64, 128, 3, False, "leaky", False),     # input-slab kernel, 64 -> 128
+    (2, 30, 7, 32, 40, 3, False, None, True),            # input-slab kernel, short rows, partial channel tile
 ]
 
 
@@ -216,7 +219,9 @@ def test_conv_dma_kernel_forced(case):
         _lib.check(L.ymx_set_option(b"dma_min_tiles", 1 << 40))
         y_small = layer(xin, residual=rin)
         _lib.check(L.ymx_set_option(b"dma_min_tiles", 0))
-        _lib.check(L.ymx_set_option(b"dma_narrow", 1))
+        for narrow in (1, 2):        # narrow layers: streamed input tiles / input slab resident in LDS
+            _lib.check(L.ymx_set_option(b"dma_narrow", narrow))
+            assert torch.equal(layer(xin, residual=rin), y_small), narrow
         for variant in (1, 2, 4, 5):  # two-stage / two workgroups per CU / staggered groups / resident input slab (3x3)
             _lib.check(L.ymx_set_option(b"dma_variant", variant))
             y = layer(xin, residual=rin)
@@ -227,6 +232,7 @@ def test_conv_dma_kernel_forced(case):
     finally:
         _lib.check(L.ymx_set_option(b"dma_min_tiles", 160))
         _lib.check(L.ymx_set_option(b"dma_variant", 5))
+        _lib.check(L.ymx_set_option(b"dma_narrow", 2))
 
 
 def test_layers_standalone():

@@ -50,7 +50,9 @@ def main():
         res = torch.randn(B, oh, ow, cout, generator=g).cuda().bfloat16()
         flops = 2.0 * B * oh * ow * k * k * cin * cout
         line = "B%d %dx%d %4d->%4d k%d s%d :" % (B, H, W, cin, cout, k, stride)
-        for kern, tiles, variant in (("128", 1 << 40, 1), ("dma1", 0, 1), ("dma2", 0, 2), ("dma2s4", 0, 2), ("dma4", 0, 4), ("dma5", 0, 5)):
+        for kern, tiles, variant in (("128", 1 << 40, 1), ("dma1", 0, 1), ("dma2", 0, 2), ("dma2s4", 0, 2), ("dma4", 0, 4), ("dma5", 0, 5), ("slab2", 0, 5)):
+            if kern == "slab2" and not (k == 3 and stride == 1 and cin in (32, 64) and cout <= 2 * cin):
+                continue
             if kern in ("dma4", "dma5") and cout <= 128:
                 continue
             if kern == "dma2s4" and cout > 64:
@@ -62,7 +64,7 @@ def main():
                 continue
             _lib.check(L.ymx_set_option(b"dma_min_tiles", tiles))
             _lib.check(L.ymx_set_option(b"dma_variant", variant))
-            _lib.check(L.ymx_set_option(b"dma_narrow", 0 if kern == "128" else 1))
+            _lib.check(L.ymx_set_option(b"dma_narrow", 0 if kern == "128" else (2 if kern == "slab2" else 1)))
             for act, use_res in ((None, False), ("mish", False), ("mish", True)):
                 layer = YOLOConv((k, k, cout), downsample=(stride == 2), activation=act, dtype=torch.bfloat16)
                 layer.build(cin, generator=g)

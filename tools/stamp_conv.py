@@ -30,11 +30,12 @@ def main():
     use_res = "res" in sys.argv[3:]
     L = _lib.lib()
     handle = ctypes.CDLL(_lib.LIB_PATH)
-    reader = getattr(handle, "ymx_debug_stamps_" + kern[:4])
+    reader = getattr(handle, "ymx_debug_stamps_" + ("dma6" if kern == "slab2" else kern[:4]))
     reader.restype = ctypes.c_int
     reader.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     _lib.check(L.ymx_set_option(b"dma_min_tiles", 0))
-    _lib.check(L.ymx_set_option(b"dma_variant", int(kern[3])))
+    _lib.check(L.ymx_set_option(b"dma_variant", 5 if kern == "slab2" else int(kern[3])))
+    _lib.check(L.ymx_set_option(b"dma_narrow", 2 if kern == "slab2" else 1))
     _lib.check(L.ymx_set_option(b"dma_stages", 4 if kern.endswith("s4") else 3))
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, H, W, cin, generator=g).cuda().bfloat16()

@@ -37,7 +37,8 @@ static bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 // 256 CUs).  YMX_DMA_MIN_TILES overrides it for experiments (a huge value disables the
 // kernel, 0 forces it).
 static long long g_dma_variant = 5;      // wide layers: 5 = resident-slab kernel for 3x3 stride 1 and the two-stage 256x256 kernel otherwise; 1-4: see ymx_set_option
-static long long g_dma_narrow = 1;       // layers of <= 128 output channels: 1 = LDS-DMA kernel, 0 = register-staged kernel
+static long long g_dma_narrow = 2;       // layers of <= 128 output channels: 2 = LDS-DMA kernels (resident input slab for
+                                         // 3x3 stride 1 with 32/64 input channels), 1 = without the slab kernel, 0 = register-staged
 static long long g_dma_min_tiles = -1;
 static long long dma_min_tiles() {
     if (g_dma_min_tiles < 0) {
@@ -125,8 +126,10 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         }
         // Narrow layers (the first backbone stages): memory-bound; the several-workgroups-
         // per-CU LDS-DMA kernel with channel tiles of 32/64/128.
-        if (dtype == YMX_BF16 && Cout <= 128 && g_dma_narrow && (a.P + 255) / 256 >= dma_min_tiles())
+        if (dtype == YMX_BF16 && Cout <= 128 && g_dma_narrow && (a.P + 255) / 256 >= dma_min_tiles()) {
+            if (g_dma_narrow == 2 && conv_slab2_eligible(a)) return launch_conv_igemm_slab2(a, s);
             return launch_conv_igemm_dma2(a, s);
+        }
         return launch_conv_igemm(a, s);
     }
     if (!aligned16(y)) return fail(YMX_EARG, "conv2d: y must be 16-byte aligned");
@@ -166,7 +169,7 @@ int ymx_set_option(const char *name, long long value) {
         return YMX_OK;
     }
     if (!strcmp(name, "dma_narrow")) {
-        if (value != 0 && value != 1) return fail(YMX_EARG, "set_option: dma_narrow must be 0 or 1");
+        if (value < 0 || value > 2) return fail(YMX_EARG, "set_option: dma_narrow must be 0, 1 or 2");
         g_dma_narrow = value;
         return YMX_OK;
     }

@@ -198,6 +198,8 @@ int launch_conv_igemm_dma2(const ConvArgs &a, hipStream_t s);
 int launch_conv_igemm_dma4(const ConvArgs &a, hipStream_t s);
 int launch_conv_igemm_halo(const ConvArgs &a, hipStream_t s);
 bool conv_halo_eligible(const ConvArgs &a);
+int launch_conv_igemm_slab2(const ConvArgs &a, hipStream_t s);
+bool conv_slab2_eligible(const ConvArgs &a);
 extern int g_dma2_stages;
 int launch_conv_direct(const ConvArgs &a, hipStream_t s);
 int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype,
