@@ -135,24 +135,68 @@ conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     YMX_STAMP(1);
 #pragma unroll
     for (int i = 0; i < NSTAGE - 1; ++i) dma(i, i);
-    vmcnt_wait<INFLIGHT>();
-    __syncthreads();
-    YMX_STAMP(2);
-    int st = 0;                                          // stage of tile s
-    auto step = [&](int s) {
-        int stn = st + NSTAGE - 1;
-        if (stn >= NSTAGE) stn -= NSTAGE;
-        dma(s + NSTAGE - 1, stn);
-        compute(st);
+    if constexpr (NI <= 4 && NSTAGE >= 4) {
+        // 32- and 64-channel tiles have registers to spare: the fragments of step s+1 are read
+        // from LDS while the MFMAs of step s run (two register sets).  A stage must then be
+        // visible one step earlier, so one stage less may be in flight when a step ends.
+        constexpr int INFLIGHT_P = NPIECE * (NSTAGE - 3);
+        vmcnt_wait<INFLIGHT_P>();                       // stages 0 and 1 have landed
+        __syncthreads();
+        YMX_STAMP(2);
+        uint4 af[2][NI], bfr[2][NJ];
+        auto load_frags = [&](int stage, auto set_tag) {
+            constexpr int SET = decltype(set_tag)::value;
+            const char *base = smem + stage * STAGE;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bfr[SET][j] = *(const uint4 *)(base + b_off + j * 1024);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) af[SET][i] = *(const uint4 *)(base + a_off + i * 1024);
+        };
+        int st = 0;                                      // stage of tile s
+        auto step = [&](int s, auto set_tag) {
+            constexpr int SET = decltype(set_tag)::value;
+            int stn = st + NSTAGE - 1;
+            if (stn >= NSTAGE) stn -= NSTAGE;
+            dma(s + NSTAGE - 1, stn);
+            const int st1 = st + 1 == NSTAGE ? 0 : st + 1;
+            load_frags(st1, std::integral_constant<int, SET ^ 1>{});     // tile s+1 (zeros past the end)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8_t, af[SET][i]), __builtin_bit_cast(bf16x8_t, bfr[SET][j]), acc[i][j], 0, 0, 0);
+            vmcnt_wait<INFLIGHT_P>();                   // tile s+2 has landed
+            __syncthreads();
+            st = st1;
+        };
+        load_frags(0, std::integral_constant<int, 0>{});
+        int s = 0;
+        for (; s + 1 < nk; s += 2) {
+            step(s, std::integral_constant<int, 0>{});
+            step(s + 1, std::integral_constant<int, 1>{});
+        }
+        if (s < nk) step(s, std::integral_constant<int, 0>{});
+    } else {
         vmcnt_wait<INFLIGHT>();
         __syncthreads();
-        st = st + 1 == NSTAGE ? 0 : st + 1;
-    };
-    for (int s = 0; s < nk - 1; ++s) step(s);
-    if constexpr (Epi::NH == 2) {
-        if (res_pre) epi_load_res<NI>(a, 0, cbase, pbase, lane, rpre[0]);   // older than the last step's pieces
+        YMX_STAMP(2);
+        int st = 0;                                      // stage of tile s
+        auto step = [&](int s) {
+            int stn = st + NSTAGE - 1;
+            if (stn >= NSTAGE) stn -= NSTAGE;
+            dma(s + NSTAGE - 1, stn);
+            compute(st);
+            vmcnt_wait<INFLIGHT>();
+            __syncthreads();
+            st = st + 1 == NSTAGE ? 0 : st + 1;
+        };
+        for (int s = 0; s < nk - 1; ++s) step(s);
+        if constexpr (Epi::NH == 2) {
+            if (res_pre) epi_load_res<NI>(a, 0, cbase, pbase, lane, rpre[0]);   // older than the last step's pieces
+        }
+        step(nk - 1);
     }
-    step(nk - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     YMX_STAMP(3);
