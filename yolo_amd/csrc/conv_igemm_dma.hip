@@ -113,16 +113,8 @@ conv_igemm_dma_kernel(const ConvArgs a, const int ntile_q, const int nk) {
                 af[(i + 1) & 1][0] = *(const uint4 *)(base + a_off + (i + 1) * 2048 + swz0);
                 af[(i + 1) & 1][1] = *(const uint4 *)(base + a_off + (i + 1) * 2048 + swz1);
             }
-#ifdef YMX_EXP_NODMA
-            if (false) {
-#else
             if (more) {
-#endif
-#ifdef YMX_EXP_HALFX
-                if (i < NXI / 2) {
-#else
                 if (i < NXI) {
-#endif
                     const bool ok = (xmask[i] & tapbit) != 0;
                     const unsigned off = ok ? (unsigned)(xoff[i] + tapoff) * 2u : OOB;
                     lds_dma16(xrsrc, sbase + (unsigned)((wave * NXI + i) * 1024), off);

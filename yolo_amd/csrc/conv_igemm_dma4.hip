@@ -169,14 +169,9 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     };
     // between the LDS reads / DMA issue of a phase and its MFMAs
     auto gate = [&]() {
-#ifndef YMX_EXP_NOWAIT
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but the four youngest pieces are in
-#endif
         barrier();
     };
-#ifdef YMX_EXP_NODMA
-#define issue(...) ((void)0)
-#endif
     for (int kt = 0; kt < nk; ++kt) {
         // phase 0: quadrant (m0, n0); issue X(n1) of tile kt+1
         read_a(kt, 0);
@@ -203,9 +198,6 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
         mfma_quadrant(I1{}, I0{});
         barrier();
     }
-#ifdef YMX_EXP_NODMA
-#undef issue
-#endif
     if (group == 0) barrier();
 
     // first half of the shortcut input (the fragment registers are free now)

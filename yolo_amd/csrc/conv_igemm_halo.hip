@@ -141,11 +141,7 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
             const int j = nh * 2 + jb;
-#ifdef YMX_EXP_NOMASK
-            const bool ok = true;
-#else
             const bool ok = live && ((fmask[j] >> tap) & 1u);
-#endif
             const int off = ok ? base + j * 2048 : zero_off;
             bfr[set][jb][0] = *(const uint4 *)(smem + off);
             bfr[set][jb][1] = *(const uint4 *)(smem + (off ^ 64));          // chunk 4 + q4
@@ -199,10 +195,6 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
     // the next tile's first pixel half in phase 3, (8, 4, 8, 4), by 8 %; cutting the phases by
     // K half instead of pixel half, (8, 8, 4, 4), by 2-3 %.)
     int cb = 0, tap = 0;
-#ifdef YMX_EXP_NODMA
-#define issue_w(...) ((void)0)
-#define issue_slab(...) ((void)0)
-#endif
     for (int kt = 0; kt < nk; ++kt) {
         const int slab = (cb & 1) * slab_bytes;
         const int tr = (tap * 11) >> 5;                     // tap / 3 for tap < 9
@@ -234,10 +226,6 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
         barrier();
         if (++tap == 9) { tap = 0; ++cb; }
     }
-#ifdef YMX_EXP_NODMA
-#undef issue_w
-#undef issue_slab
-#endif
     if (group == 0) barrier();
 
     // first half of the shortcut input (the fragment registers are free now)
