@@ -140,16 +140,18 @@ from yolo_amd import dist as D
 from yolo_amd.utils import Detections
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
 rank = dist.get_rank()
-GB, T = 5, 4
-g = torch.Generator().manual_seed(7)
-full = Detections(torch.rand(GB, T, 4, generator=g), torch.rand(GB, T, generator=g),
-                  torch.randint(0, 80, (GB, T), generator=g).float(),
-                  torch.randint(0, T + 1, (GB,), generator=g, dtype=torch.int32),
-                  torch.randint(-1, 999, (GB, T), generator=g, dtype=torch.int32))
-s, c = D.shard_range(GB, rank, 2)
-mine = Detections(*[t[s:s + c].clone() for t in full], full.keep_idx[s:s + c].clone())
-got = D.all_gather_detections(mine, GB)
-ok = all(torch.equal(a, b) for a, b in zip(tuple(full) + (full.keep_idx,), tuple(got) + (got.keep_idx,)))
+T = 4
+ok = True
+for GB in (5, 4, 1):                      # uneven shards, even shards, a rank with no image
+    g = torch.Generator().manual_seed(7 + GB)
+    full = Detections(torch.rand(GB, T, 4, generator=g), torch.rand(GB, T, generator=g),
+                      torch.randint(0, 80, (GB, T), generator=g).float(),
+                      torch.randint(0, T + 1, (GB,), generator=g, dtype=torch.int32),
+                      torch.randint(-1, 999, (GB, T), generator=g, dtype=torch.int32))
+    s, c = D.shard_range(GB, rank, 2)
+    mine = Detections(*[t[s:s + c].clone() for t in full], full.keep_idx[s:s + c].clone())
+    got = D.all_gather_detections(mine, GB)
+    ok = ok and all(torch.equal(a, b) for a, b in zip(tuple(full) + (full.keep_idx,), tuple(got) + (got.keep_idx,)))
 dist.barrier(); dist.destroy_process_group()
 sys.exit(0 if ok else 3)
 """

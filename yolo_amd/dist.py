@@ -28,16 +28,12 @@ def pack_detections(det, rows):
     boxes, scores, classes, valid = det
     keep = det.keep_idx
     b, t = scores.shape
-    rec = torch.zeros((rows, t * 7 + 1), device=boxes.device, dtype=torch.float32)
-    rec[:b, 0:4 * t] = boxes.reshape(b, 4 * t)
-    rec[:b, 4 * t:5 * t] = scores
-    rec[:b, 5 * t:6 * t] = classes
-    pad_keep = torch.full((rows, t), -1, device=boxes.device, dtype=torch.int32)
-    pad_keep[:b] = keep
-    rec[:, 6 * t:7 * t] = pad_keep.view(torch.float32)
-    pad_valid = torch.zeros((rows,), device=boxes.device, dtype=torch.int32)
-    pad_valid[:b] = valid
-    rec[:, 7 * t] = pad_valid.view(torch.float32)
+    rec = torch.cat([boxes.reshape(b, 4 * t), scores, classes, keep.view(torch.float32),
+                     valid.view(torch.float32).reshape(b, 1)], dim=1)        # one kernel
+    if rows > b:                                                             # uneven shards only
+        pad = torch.zeros((rows - b, t * 7 + 1), device=rec.device, dtype=torch.float32)
+        pad[:, 6 * t:7 * t] = torch.full((rows - b, t), -1, device=rec.device, dtype=torch.int32).view(torch.float32)
+        rec = torch.cat([rec, pad], dim=0)
     return rec
 
 
@@ -71,12 +67,15 @@ def all_gather_detections(det, global_batch, group=None):
     device = rec.device
     if rec.is_cuda and dist.get_backend(group) != "nccl":
         rec = rec.cpu()             # gloo gathers host tensors only; RCCL takes the device buffer as is
-    out = [torch.empty_like(rec) for _ in range(world)]
-    dist.all_gather(out, rec, group=group)
-    if out[0].device != device:
-        out = [o.to(device) for o in out]
+    out = torch.empty((world * rows, rec.shape[1]), device=rec.device, dtype=rec.dtype)
+    dist.all_gather_into_tensor(out, rec, group=group)           # one collective, one output buffer
+    if out.device != device:
+        out = out.to(device)
+    if global_batch == world * rows:                             # even shards: the buffer is already in order
+        return unpack_detections(out, t)
+    out = out.view(world, rows, -1)
     parts = []
     for r in range(world):
         _, cnt = shard_range(global_batch, r, world)
-        parts.append(out[r][:cnt])
+        parts.append(out[r, :cnt])
     return unpack_detections(torch.cat(parts, dim=0), t)
