@@ -117,6 +117,10 @@ typedef struct ymx_op {
     int32_t dtype, x_dtype, out_dtype;
     int32_t x_ld, res_ld, y_ld;
     int32_t C1, C2;               /* upsample2x_concat only */
+    int32_t min_tiles;            /* conv only: fewest 256-wide tiles for which the large-tile LDS-DMA
+                                     kernels are chosen; 0 = the library's "dma_min_tiles" option.
+                                     Programs meant to share the GPU with another stream's program
+                                     set it lower (fewer, larger tiles: less weight traffic). */
     const void *x, *w, *scale, *shift, *residual;   /* residual doubles as skip */
     void *y;
 } ymx_op;

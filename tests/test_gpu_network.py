@@ -178,6 +178,59 @@ def test_608_geometry_batch_invariance():
             assert torch.equal(u[i:i + 1], v)
 
 
+def test_concurrent_sub_batches_equal_whole_batch():
+    """A batch cut into sub-batches that run concurrently on separate streams gives the
+    same bits as the whole batch as one program: heads, detections and keep indices; twice
+    in a row (buffers and streams are reused), then with a different cut."""
+    from yolo_amd import Detector
+    C = 80
+    x = _image(7, 160).to(DEV)
+    whole = Detector(num_classes=C, dtype=torch.bfloat16, seed=5, split="off").to(DEV)
+    whole.calibrate_(x[:2].contiguous())
+    want = whole(x)
+    want = [t.clone() for t in want] + [want.keep_idx.clone()]
+    want_heads = [h.clone() for h in whole.forward_heads(x)]
+    assert int(want[3].min()) > 0
+    for cut in ((5, 2), (3, 3, 1), (1, 6)):
+        det = Detector(num_classes=C, dtype=torch.bfloat16, seed=5, split=cut).to(DEV)
+        det.calibrate_(x[:2].contiguous())
+        for _ in range(2):
+            got = det(x)
+            plan = det._plan(7, 160, x.dtype, x.device)
+            assert plan.sizes == cut and len(plan.parts) == len(cut)
+            got = [t.clone() for t in got] + [got.keep_idx.clone()]
+            for u, v in zip(want, got):
+                assert torch.equal(u, v)
+        for u, v in zip(want_heads, det.forward_heads(x)):
+            assert torch.equal(u, v)
+        # a batch the cut does not sum to runs as one program
+        one = det(x[:2].contiguous())
+        assert det._plan(2, 160, x.dtype, x.device).sizes == (2,)
+        for u, v in zip(want, list(one) + [one.keep_idx]):
+            assert torch.equal(u[:2], v)
+
+
+def test_auto_cut_is_timed_once_and_exact():
+    """split="auto" on a batch large enough to be cut: whichever cut the timing picks, the
+    results equal the whole-batch program, and the choice is cached per input shape."""
+    from yolo_amd import Detector
+    C = 80
+    x = _image(16, 416).to(DEV)
+    det = Detector(num_classes=C, dtype=torch.bfloat16, seed=6).to(DEV)
+    det.calibrate_(x[:2].contiguous())
+    got = det(x)
+    got = [t.clone() for t in got] + [got.keep_idx.clone()]
+    plan = det._plan(16, 416, x.dtype, x.device)
+    assert sum(plan.sizes) == 16 and plan is det._plan(16, 416, x.dtype, x.device)
+    whole = Detector(num_classes=C, dtype=torch.bfloat16, seed=6, split="off").to(DEV)
+    whole.calibrate_(x[:2].contiguous())
+    want = whole(x)
+    for u, v in zip(list(want) + [want.keep_idx], got):
+        assert torch.equal(u, v)
+    with pytest.raises(ValueError):
+        Detector(num_classes=C, split=(4, 0))
+
+
 def test_stress_geometry_scaled():
     """NMS stress geometry (1280^2-equivalent heads, 100 800 candidates, 80 classes,
     threshold 0.001) at batch 2: decode+filter+NMS vs the C oracle on the GPU's decode."""

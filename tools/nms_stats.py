@@ -10,7 +10,7 @@ from yolo_amd.engine import Detector            # noqa: E402
 
 def main():
     torch.manual_seed(0)
-    det = Detector(num_classes=80, dtype=torch.bfloat16, seed=0).cuda()
+    det = Detector(num_classes=80, dtype=torch.bfloat16, seed=0, split="off").cuda()
     g = torch.Generator().manual_seed(1)
     x = torch.rand(64, 416, 416, 3, generator=g).cuda()
     det.calibrate_(x[:8])
@@ -18,7 +18,7 @@ def main():
     torch.cuda.synchronize()
     plan = det._plan(64, 416, x.dtype, x.device)
     counts = plan.counts.cpu()
-    sc = plan.scores_cm                       # [B, C, cap]
+    sc = plan.parts[0].scores_cm              # [B, C, cap]
     thr = det.score_threshold
     print("score_thr", thr, "iou_thr", det.iou_threshold, "per_class", det.max_outputs_per_class, "total", det.max_outputs)
     print("survivors/image: mean %.0f max %d cap %d" % (counts.float().mean(), counts.max(), plan.cap))

@@ -21,7 +21,7 @@ class ymx_op(ctypes.Structure):
     """Mirror of ``struct ymx_op`` in include/ymx.h."""
     _fields_ = [(n, ctypes.c_int32) for n in
                 ("kind", "B", "H", "W", "Cin", "Cout", "k", "stride", "act", "dtype", "x_dtype",
-                 "out_dtype", "x_ld", "res_ld", "y_ld", "C1", "C2")] + \
+                 "out_dtype", "x_ld", "res_ld", "y_ld", "C1", "C2", "min_tiles")] + \
                [(n, ctypes.c_void_p) for n in ("x", "w", "scale", "shift", "residual", "y")]
 
 

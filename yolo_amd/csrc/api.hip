@@ -51,8 +51,10 @@ static long long dma_min_tiles() {
 static int conv_impl(const void *x, const void *w, const void *scale, const void *shift,
                      const void *residual, void *y, int B, int H, int W, int Cin, int Cout, int k,
                      int stride, int act, int dtype, int x_dtype, int out_dtype, int x_ld, int res_ld,
-                     int y_ld, hipStream_t s) {
+                     int y_ld, hipStream_t s, int op_min_tiles = 0) {
     if (!x || !w || !y) return fail(YMX_EARG, "conv2d: null x, w or y");
+    if (op_min_tiles < 0) return fail(YMX_EARG, "conv2d: negative min_tiles");
+    const long long min_tiles = op_min_tiles > 0 ? op_min_tiles : dma_min_tiles();
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(YMX_EARG, "conv2d: non-positive size");
     if (k < 1 || k > 5 || (k & 1) == 0) return fail(YMX_EUNSUPPORTED, "conv2d: kernel size %d (odd, <= 5)", k);
     if (stride != 1 && stride != 2) return fail(YMX_EUNSUPPORTED, "conv2d: stride %d (1 or 2)", stride);
@@ -109,7 +111,7 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         // and has enough of them to occupy the chip; the 128x128 kernel otherwise.
         if (dtype == YMX_BF16 && Cout > 128) {
             const long long tiles = ((long long)(a.P + 255) / 256) * ((Cout + 255) / 256);
-            if (tiles >= dma_min_tiles()) {
+            if (tiles >= min_tiles) {
                 switch (g_dma_variant) {
                 case 1: return launch_conv_igemm_dma(a, s);
                 case 2: return launch_conv_igemm_dma2(a, s);
@@ -126,7 +128,7 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         }
         // Narrow layers (the first backbone stages): memory-bound; the several-workgroups-
         // per-CU LDS-DMA kernel with channel tiles of 32/64/128.
-        if (dtype == YMX_BF16 && Cout <= 128 && g_dma_narrow && (a.P + 255) / 256 >= dma_min_tiles()) {
+        if (dtype == YMX_BF16 && Cout <= 128 && g_dma_narrow && (a.P + 255) / 256 >= min_tiles) {
             if (g_dma_narrow == 2 && conv_slab2_eligible(a)) return launch_conv_igemm_slab2(a, s);
             return launch_conv_igemm_dma2(a, s);
         }
@@ -224,7 +226,7 @@ int ymx_run_program(const ymx_op *ops, int n_ops, void *stream) {
         int rc;
         if (o.kind == 1)
             rc = conv_impl(o.x, o.w, o.scale, o.shift, o.residual, o.y, o.B, o.H, o.W, o.Cin, o.Cout, o.k, o.stride,
-                           o.act, o.dtype, o.x_dtype, o.out_dtype, o.x_ld, o.res_ld, o.y_ld, (hipStream_t)stream);
+                           o.act, o.dtype, o.x_dtype, o.out_dtype, o.x_ld, o.res_ld, o.y_ld, (hipStream_t)stream, o.min_tiles);
         else if (o.kind == 2)
             rc = ymx_upsample2x_concat(o.residual, o.x, o.y, o.B, o.H, o.W, o.C1, o.C2, o.dtype, stream);
         else

@@ -28,10 +28,24 @@ class _Plan(object):
     pass
 
 
+# Tile threshold (see ymx_op.min_tiles) for programs that share the GPU with another
+# stream's program: with the chip already busy, fewer and larger tiles win.
+_SHARED_MIN_TILES = 80
+
+
 class Detector(nn.Module):
     def __init__(self, num_classes=80, dtype=torch.bfloat16, seed=0, max_outputs_per_class=32, max_outputs=32,
-                 iou_threshold=0.45, score_threshold=0.25):
+                 iou_threshold=0.45, score_threshold=0.25, split="auto"):
+        """``split``: how a batch is cut into sub-batches that run concurrently on separate
+        HIP streams (the tail of one sub-batch's launch overlaps the other's work):
+        "auto" = time a few cuts once per input shape and keep the fastest, "off" = never,
+        or a tuple of sub-batch sizes used for batches of exactly their sum."""
         super().__init__()
+        if not (split in ("auto", "off") or (isinstance(split, (tuple, list)) and split and
+                                            all(isinstance(n, int) and n > 0 for n in split))):
+            raise ValueError("split must be 'auto', 'off' or a tuple of positive sub-batch sizes")
+        self.split = split
+        self._side_streams = []
         self.num_classes = num_classes
         self.dtype = dtype
         self.backbone = Darknet53(dtype=dtype, seed=seed)
@@ -96,26 +110,24 @@ class Detector(nn.Module):
         return self
 
     # ------------------------------------------------------------------ planning
-    def _plan(self, B, S, x_dtype, device):
-        key = (B, S, x_dtype, str(device))
-        plan = self._plans.get(key)
-        if plan is not None:
-            return plan
+    def _build_part(self, plan, n, start, S, x_dtype, device, min_tiles):
+        """Program, activation buffers and post-processing buffers for images
+        [start, start + n) of the batch; outputs land in slices of the plan's buffers."""
         cdt = self.dtype
         code = _lib.dtype_code(cdt)
         ops = []
         keep = []                       # tensors the program points at
 
         def buf(h, w, c, dtype=cdt):
-            t = torch.empty((B, h, w, c), device=device, dtype=dtype)
+            t = torch.empty((n, h, w, c), device=device, dtype=dtype)
             keep.append(t)
             return t
 
-        def conv(layer, x, h, w, residual=None, x_code=code, out_dtype=cdt, pad_out=False):
+        def conv(layer, x, h, w, residual=None, x_code=code, out_dtype=cdt, head=None):
             wp, scale, shift, _src = layer.packed(cdt)
             oh, ow = layer.output_hw(h, w)
             cout = layer.filters
-            if pad_out and cout % 8:
+            if head is not None and cout % 8:
                 # Output maps whose channel count is not a multiple of 8 (255 for 80 classes)
                 # are computed as the next multiple: the packed weights already hold zero rows
                 # up to a multiple of 128, scale/shift get zeros, so the extra channels are
@@ -128,13 +140,20 @@ class Detector(nn.Module):
                 if shift is not None:
                     shift = torch.cat([shift, shift.new_zeros(extra)])
             keep.extend([wp, scale, shift])
-            y = buf(oh, ow, cout, out_dtype)
+            if head is None:
+                y = buf(oh, ow, cout, out_dtype)
+            else:
+                # the three output maps are whole-batch buffers owned by the plan
+                if plan.padded[head] is None:
+                    plan.padded[head] = torch.empty((plan.B, oh, ow, cout), device=device, dtype=out_dtype)
+                y = plan.padded[head][start:start + n]
             o = _lib.ymx_op()
             o.kind = 1
-            o.B, o.H, o.W, o.Cin, o.Cout = B, h, w, layer.in_channels, cout
+            o.B, o.H, o.W, o.Cin, o.Cout = n, h, w, layer.in_channels, cout
             o.k, o.stride, o.act = layer.kernel_size, 2 if layer.downsample else 1, layer.act_code
             o.dtype, o.x_dtype, o.out_dtype = code, x_code, _lib.dtype_code(out_dtype)
             o.x_ld = o.res_ld = o.y_ld = 0
+            o.min_tiles = min_tiles
             o.x = None if x is None else x.data_ptr()
             o.w = wp.data_ptr()
             o.scale = None if scale is None else scale.data_ptr()
@@ -150,7 +169,7 @@ class Detector(nn.Module):
             y = buf(2 * h, 2 * w, c1 + c2)
             o = _lib.ymx_op()
             o.kind = 2
-            o.B, o.H, o.W, o.C1, o.C2, o.dtype = B, h, w, c1, c2, code
+            o.B, o.H, o.W, o.C1, o.C2, o.dtype = n, h, w, c1, c2, code
             o.residual, o.x, o.y = skip.data_ptr(), x.data_ptr(), y.data_ptr()
             ops.append(o)
             return y
@@ -173,48 +192,135 @@ class Detector(nn.Module):
         s3, h3, w3 = run_stack(bb.layer_stack_3, s2, h2, w2)
         x, _, _ = run_stack(hd.layer_stack_1, s3, h3, w3)
         l, _, _ = conv(hd.lbbox_layer_stack[0], x, h3, w3)
-        l, _, _ = conv(hd.lbbox_layer_stack[1], l, h3, w3, out_dtype=hd.out_dtype, pad_out=True)
+        l, _, _ = conv(hd.lbbox_layer_stack[1], l, h3, w3, out_dtype=hd.out_dtype, head=2)
         x = upcat(s2, x, h3, w3, s2.shape[-1], x.shape[-1])
         x, _, _ = run_stack(hd.layer_stack_2, x, h2, w2)
         m, _, _ = conv(hd.mbbox_layer_stack[0], x, h2, w2)
-        m, _, _ = conv(hd.mbbox_layer_stack[1], m, h2, w2, out_dtype=hd.out_dtype, pad_out=True)
+        m, _, _ = conv(hd.mbbox_layer_stack[1], m, h2, w2, out_dtype=hd.out_dtype, head=1)
         s = upcat(s1, x, h2, w2, s1.shape[-1], x.shape[-1])
         s, _, _ = run_stack(list(hd.sbbox_layer_stack)[:-1], s, h1, w1)
-        s, _, _ = conv(hd.sbbox_layer_stack[-1], s, h1, w1, out_dtype=hd.out_dtype, pad_out=True)
+        s, _, _ = conv(hd.sbbox_layer_stack[-1], s, h1, w1, out_dtype=hd.out_dtype, head=0)
 
-        plan = _Plan()
-        plan.ops = (_lib.ymx_op * len(ops))(*ops)
-        plan.n_ops = len(ops)
-        plan.keep = keep
+        part = _Plan()
+        part.B, part.start = n, start
+        part.ops = (_lib.ymx_op * len(ops))(*ops)
+        part.n_ops = len(ops)
+        part.keep = keep
+        part.x_offset = start * S * S * 3 * torch.empty((), dtype=x_dtype).element_size()
         C = self.num_classes
-        padded = (s, m, l)                                  # [B,S,S,cell_ld] buffers the convs write
-        plan.heads = tuple(t[..., :3 * (5 + C)] for t in padded)    # what callers see: [B,S,S,3*(5+C)]
-        plan.head_dtype = s.dtype
-        plan.first_is_direct = True
-        # post-processing buffers
+        padded = (s, m, l)                                  # this part's slices of the [B,S,S,cell_ld] maps
+        part.head_dtype = s.dtype
         anc = _utils.default_anchors()
-        plan.scales = _utils._Scales(padded, _YOLO["strides"], _YOLO["xyscale"], anc,
+        part.scales = _utils._Scales(padded, _YOLO["strides"], _YOLO["xyscale"], anc,
                                      cell_ld=[t.shape[-1] for t in padded])
-        cap = _utils._round4(plan.scales.N)
-        plan.cap = cap
+        cap = _utils._round4(part.scales.N)
+        part.cap = cap
         f32, i32 = torch.float32, torch.int32
-        plan.boxes = torch.empty((B, cap, 4), device=device, dtype=f32)
-        plan.scores_cm = torch.empty((B, C, cap), device=device, dtype=f32)
-        plan.src_idx = torch.empty((B, cap), device=device, dtype=i32)
-        plan.counts = torch.empty((B,), device=device, dtype=i32)
+        part.boxes = torch.empty((n, cap, 4), device=device, dtype=f32)
+        part.scores_cm = torch.empty((n, C, cap), device=device, dtype=f32)
+        part.src_idx = torch.empty((n, cap), device=device, dtype=i32)
         L = _lib.lib()
-        plan.dec_ws_bytes = L.ymx_decode_workspace_bytes(B, plan.scales.n, plan.scales.S)
-        plan.dec_ws = torch.empty((plan.dec_ws_bytes,), device=device, dtype=torch.uint8)
-        T = self.max_outputs
+        part.dec_ws_bytes = L.ymx_decode_workspace_bytes(n, part.scales.n, part.scales.S)
+        part.dec_ws = torch.empty((part.dec_ws_bytes,), device=device, dtype=torch.uint8)
+        part.nms_ws_bytes = L.ymx_nms_workspace_bytes(n, C, self.max_outputs_per_class)
+        part.nms_ws = torch.empty((max(part.nms_ws_bytes, 16),), device=device, dtype=torch.uint8)
+        part.stream = part.done = None
+        return part
+
+    def _build_plan(self, sizes, S, x_dtype, device):
+        """One plan = the batch cut into len(sizes) consecutive sub-batches, each with its own
+        program; sub-batches after the first run on side streams, concurrently."""
+        B = sum(sizes)
+        plan = _Plan()
+        plan.B, plan.sizes = B, tuple(sizes)
+        plan.padded = [None, None, None]
+        T, C = self.max_outputs, self.num_classes
+        f32, i32 = torch.float32, torch.int32
+        plan.counts = torch.empty((B,), device=device, dtype=i32)
         plan.out_boxes = torch.empty((B, T, 4), device=device, dtype=f32)
         plan.out_scores = torch.empty((B, T), device=device, dtype=f32)
         plan.out_classes = torch.empty((B, T), device=device, dtype=f32)
         plan.out_valid = torch.empty((B,), device=device, dtype=i32)
         plan.out_keep = torch.empty((B, T), device=device, dtype=i32)
-        plan.nms_ws_bytes = L.ymx_nms_workspace_bytes(B, C, self.max_outputs_per_class)
-        plan.nms_ws = torch.empty((max(plan.nms_ws_bytes, 16),), device=device, dtype=torch.uint8)
+        shared = len(sizes) > 1
+        plan.parts = []
+        start = 0
+        for i, n in enumerate(sizes):
+            part = self._build_part(plan, n, start, S, x_dtype, device, _SHARED_MIN_TILES if shared else 0)
+            sl = slice(start, start + n)
+            part.counts = plan.counts[sl]
+            part.out = tuple(t[sl] for t in (plan.out_boxes, plan.out_scores, plan.out_classes, plan.out_valid,
+                                             plan.out_keep))
+            if i > 0:
+                while len(self._side_streams) < i:
+                    self._side_streams.append(torch.cuda.Stream(device=device))
+                part.stream = self._side_streams[i - 1]
+                part.done = torch.cuda.Event()
+            plan.parts.append(part)
+            start += n
+        plan.start_event = torch.cuda.Event() if shared else None
+        plan.heads = tuple(t[..., :3 * (5 + C)] for t in plan.padded)    # what callers see: [B,S,S,3*(5+C)]
+        # single-part views kept for callers that inspect a plan (benchmarks, tests)
+        first = plan.parts[0]
+        plan.scales, plan.cap, plan.head_dtype = first.scales, first.cap, first.head_dtype
+        return plan
+
+    def _candidate_splits(self, B, S):
+        """Sub-batch sizes worth timing for a batch of B images of side S."""
+        if isinstance(self.split, (tuple, list)):
+            return [tuple(self.split)] if sum(self.split) == B else [(B,)]
+        if self.split == "off" or B < 16 or B * S * S < 16 * 416 * 416:
+            return [(B,)]
+        cands = [(B,)]
+        for num, den in ((3, 4), (5, 8), (1, 2)):
+            a = B * num // den
+            if 0 < a < B and (a, B - a) not in cands:
+                cands.append((a, B - a))
+        return cands
+
+    def _plan(self, B, S, x_dtype, device, x=None):
+        key = (B, S, x_dtype, str(device))
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
+        cands = self._candidate_splits(B, S)
+        if len(cands) == 1:
+            plan = self._build_plan(cands[0], S, x_dtype, device)
+        else:
+            # Which cut of the batch is fastest depends on how the tile counts of the layers
+            # fall on the 256 CUs, so it is measured, once per input shape.  Results do not
+            # depend on the cut (every image is computed by the same arithmetic).
+            if x is None:
+                x = torch.rand((B, S, S, 3), device=device).to(x_dtype)
+            whole = self._build_plan(cands[0], S, x_dtype, device)
+            best, best_ms = whole, self._time_plan(whole, x, S) * 0.98     # a cut must win by 2 %
+            for _attempt in range(4):
+                for sizes in cands[1:]:
+                    cand = self._build_plan(sizes, S, x_dtype, device)
+                    ms = self._time_plan(cand, x, S)
+                    if ms < best_ms:
+                        best, best_ms = cand, ms
+                    del cand
+                if best is not whole:
+                    break
+                # No cut won.  A side stream that the runtime placed on the hardware queue of
+                # the current stream cannot overlap with it (measured: about one stream in
+                # four, and stable for the life of the stream), so try with fresh ones.
+                self._side_streams = []
+            plan = best
         self._plans[key] = plan
         return plan
+
+    def _time_plan(self, plan, x, S, warm=2, steps=4):
+        for _ in range(warm):
+            self._run(plan, x, S, True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            self._run(plan, x, S, True)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / steps
 
     # ------------------------------------------------------------------ execution
     def _check_input(self, x):
@@ -227,29 +333,58 @@ class Detector(nn.Module):
             raise ValueError("images must be float32 or bfloat16")
         return x.contiguous()
 
+    def _run_part(self, part, x_ptr, image_size, post):
+        part.ops[0].x = x_ptr + part.x_offset
+        _lib.check(_lib.lib().ymx_run_program(part.ops, part.n_ops, _lib.stream()))
+        if post:
+            self._postprocess_part(part, image_size)
+
+    def _run(self, plan, x, image_size, post):
+        """All sub-batches of the plan: the first on the current stream, the others on side
+        streams that start after the work already queued on the current stream and are
+        joined back into it before this returns."""
+        parts = plan.parts
+        x_ptr = x.data_ptr()
+        if len(parts) > 1:
+            main = torch.cuda.current_stream()
+            plan.start_event.record(main)
+            for part in parts[1:]:
+                part.stream.wait_event(plan.start_event)
+                with torch.cuda.stream(part.stream):
+                    self._run_part(part, x_ptr, image_size, post)
+                    part.done.record(part.stream)
+        self._run_part(parts[0], x_ptr, image_size, post)
+        for part in parts[1:]:
+            torch.cuda.current_stream().wait_event(part.done)
+
     def forward_heads(self, x):
         """images [B,S,S,3] -> (sbbox, mbbox, lbbox) raw conv maps (plan-owned buffers)."""
         x = self._check_input(x)
-        plan = self._plan(x.shape[0], x.shape[1], x.dtype, x.device)
-        plan.ops[0].x = x.data_ptr()
-        _lib.check(_lib.lib().ymx_run_program(plan.ops, plan.n_ops, _lib.stream()))
+        plan = self._plan(x.shape[0], x.shape[1], x.dtype, x.device, x)
+        self._run(plan, x, x.shape[1], False)
         return plan.heads
 
-    def postprocess(self, plan, image_size):
+    def _postprocess_part(self, part, image_size):
         L = _lib.lib()
-        sc = plan.scales
-        B, C = plan.boxes.shape[0], self.num_classes
-        _lib.check(L.ymx_decode_filter_strided(sc.ptrs, sc.cell_ld, sc.n, sc.S, B, C, _lib.dtype_code(plan.head_dtype),
+        sc = part.scales
+        B, C = part.B, self.num_classes
+        out_boxes, out_scores, out_classes, out_valid, out_keep = part.out
+        _lib.check(L.ymx_decode_filter_strided(sc.ptrs, sc.cell_ld, sc.n, sc.S, B, C, _lib.dtype_code(part.head_dtype),
                                                sc.anchors, sc.strides, sc.xyscale, 1, float(self.score_threshold),
-                                               float(image_size), _lib.ptr(plan.boxes), _lib.ptr(plan.scores_cm),
-                                               _lib.ptr(plan.src_idx), _lib.ptr(plan.counts), plan.cap,
-                                               _lib.ptr(plan.dec_ws), plan.dec_ws_bytes, _lib.stream()))
-        _lib.check(L.ymx_nms_combined(_lib.ptr(plan.boxes), _lib.ptr(plan.scores_cm), _lib.ptr(plan.counts),
-                                      _lib.ptr(plan.src_idx), B, plan.cap, C, int(self.max_outputs_per_class),
+                                               float(image_size), _lib.ptr(part.boxes), _lib.ptr(part.scores_cm),
+                                               _lib.ptr(part.src_idx), _lib.ptr(part.counts), part.cap,
+                                               _lib.ptr(part.dec_ws), part.dec_ws_bytes, _lib.stream()))
+        _lib.check(L.ymx_nms_combined(_lib.ptr(part.boxes), _lib.ptr(part.scores_cm), _lib.ptr(part.counts),
+                                      _lib.ptr(part.src_idx), B, part.cap, C, int(self.max_outputs_per_class),
                                       int(self.max_outputs), float(self.iou_threshold), float(self.score_threshold),
-                                      _lib.ptr(plan.out_boxes), _lib.ptr(plan.out_scores), _lib.ptr(plan.out_classes),
-                                      _lib.ptr(plan.out_valid), _lib.ptr(plan.out_keep), _lib.ptr(plan.nms_ws),
-                                      plan.nms_ws_bytes, _lib.stream()))
+                                      _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_classes),
+                                      _lib.ptr(out_valid), _lib.ptr(out_keep), _lib.ptr(part.nms_ws),
+                                      part.nms_ws_bytes, _lib.stream()))
+
+    def postprocess(self, plan, image_size):
+        """decode + filter + combined NMS of the plan's head maps, on the current stream."""
+        for part in plan.parts:
+            self._postprocess_part(part, image_size)
         return _utils.Detections(plan.out_boxes, plan.out_scores, plan.out_classes, plan.out_valid, plan.out_keep)
 
     def forward(self, x, image_size=None):
@@ -258,7 +393,6 @@ class Detector(nn.Module):
         The returned tensors are the plan's output buffers: they are overwritten by
         the next call with the same input shape."""
         x = self._check_input(x)
-        plan = self._plan(x.shape[0], x.shape[1], x.dtype, x.device)
-        plan.ops[0].x = x.data_ptr()
-        _lib.check(_lib.lib().ymx_run_program(plan.ops, plan.n_ops, _lib.stream()))
-        return self.postprocess(plan, x.shape[1] if image_size is None else image_size)
+        plan = self._plan(x.shape[0], x.shape[1], x.dtype, x.device, x)
+        self._run(plan, x, x.shape[1] if image_size is None else image_size, True)
+        return _utils.Detections(plan.out_boxes, plan.out_scores, plan.out_classes, plan.out_valid, plan.out_keep)
