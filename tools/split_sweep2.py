@@ -25,7 +25,7 @@ def timeit(steps=10):
 
 for inst in range(12):
     det._plans = {}
-    det._side_streams = []
+    det._side_streams = {}
     t0 = time.perf_counter()
     det(x)
     torch.cuda.synchronize()

@@ -45,7 +45,7 @@ class Detector(nn.Module):
                                             all(isinstance(n, int) and n > 0 for n in split))):
             raise ValueError("split must be 'auto', 'off' or a tuple of positive sub-batch sizes")
         self.split = split
-        self._side_streams = []
+        self._side_streams = {}             # device -> streams of the sub-batches after the first
         self.num_classes = num_classes
         self.dtype = dtype
         self.backbone = Darknet53(dtype=dtype, seed=seed)
@@ -252,9 +252,10 @@ class Detector(nn.Module):
             part.out = tuple(t[sl] for t in (plan.out_boxes, plan.out_scores, plan.out_classes, plan.out_valid,
                                              plan.out_keep))
             if i > 0:
-                while len(self._side_streams) < i:
-                    self._side_streams.append(torch.cuda.Stream(device=device))
-                part.stream = self._side_streams[i - 1]
+                side = self._side_streams.setdefault(str(device), [])
+                while len(side) < i:
+                    side.append(torch.cuda.Stream(device=device))
+                part.stream = side[i - 1]
                 part.done = torch.cuda.Event()
             plan.parts.append(part)
             start += n
@@ -306,7 +307,7 @@ class Detector(nn.Module):
                 # No cut won.  A side stream that the runtime placed on the hardware queue of
                 # the current stream cannot overlap with it (measured: about one stream in
                 # four, and stable for the life of the stream), so try with fresh ones.
-                self._side_streams = []
+                self._side_streams.pop(str(device), None)
             plan = best
         self._plans[key] = plan
         return plan
