@@ -235,6 +235,62 @@ def test_conv_dma_kernel_forced(case):
         _lib.check(L.ymx_set_option(b"dma_narrow", 2))
 
 
+RACE_SHAPES = [   # B, H, W, Cin, Cout, k, stride: every LDS-DMA kernel family at benchmark-sized layers
+    (64, 26, 26, 256, 512, 3, 1), (48, 13, 13, 512, 1024, 3, 1), (64, 52, 52, 1024, 512, 1, 1),
+    (64, 26, 26, 512, 1024, 3, 2), (64, 208, 208, 32, 64, 3, 1), (48, 104, 104, 64, 128, 3, 1),
+    (64, 104, 104, 128, 64, 1, 1),
+]
+
+
+def test_conv_kernels_repeat_bit_exact_under_concurrent_load():
+    """Race screen: each LDS-DMA kernel, at benchmark-sized layers, run repeatedly while a
+    second stream keeps the GPU busy with other convolutions (the engine runs two programs
+    at once, so workgroups start at irregular times next to foreign traffic); every output
+    must equal the register-staged kernel's bit for bit.  tools/race_screen.py is the long
+    version (all shapes, thousands of repetitions)."""
+    from yolo_amd import _lib
+    from yolo_amd.layers import YOLOConv
+    L = _lib.lib()
+
+    def set_kernel(tiles, variant, narrow):
+        _lib.check(L.ymx_set_option(b"dma_min_tiles", tiles))
+        _lib.check(L.ymx_set_option(b"dma_variant", variant))
+        _lib.check(L.ymx_set_option(b"dma_narrow", narrow))
+
+    g = torch.Generator().manual_seed(77)
+    side = torch.cuda.Stream()
+    px = torch.randn(24, 26, 26, 256, generator=g).to(DEV).bfloat16()
+    pl = YOLOConv((3, 3, 512), activation="mish", dtype=torch.bfloat16)
+    pl.build(256, generator=g)
+    pl.to(DEV)
+    try:
+        for (B, H, W, cin, cout, k, stride) in RACE_SHAPES:
+            x = torch.randn(B, H, W, cin, generator=g).to(DEV).bfloat16()
+            oh, ow = (H, W) if stride == 1 else ((H + 1 - k) // 2 + 1, (W + 1 - k) // 2 + 1)
+            res = torch.randn(B, oh, ow, cout, generator=g).to(DEV).bfloat16()
+            layer = YOLOConv((k, k, cout), downsample=(stride == 2), activation="mish", dtype=torch.bfloat16)
+            layer.build(cin, generator=g)
+            with torch.no_grad():
+                layer.kernel.mul_(10.0)
+            layer.to(DEV)
+            set_kernel(1 << 40, 1, 0)
+            ref = layer(x, residual=res).view(torch.int16).clone()
+            torch.cuda.synchronize()
+            variants = ((1, 1), (4, 1), (5, 2)) if cout > 128 else ((5, 1), (5, 2))
+            for variant, narrow in variants:
+                bad = torch.zeros((), device=DEV, dtype=torch.int64)
+                for it in range(25):
+                    set_kernel(0, variant, narrow)
+                    bad += (layer(x, residual=res).view(torch.int16) != ref).sum()
+                    with torch.cuda.stream(side):
+                        set_kernel(0, 5, 2)
+                        pl(px)
+                side.synchronize()
+                assert int(bad.item()) == 0, (B, H, W, cin, cout, k, stride, variant, narrow)
+    finally:
+        set_kernel(160, 5, 2)
+
+
 def test_layers_standalone():
     from yolo_amd import layers
     g = torch.Generator().manual_seed(2)
