@@ -143,7 +143,11 @@ int ymx_run_program(const ymx_op *ops /* host */, int n_ops, void *stream);
  * head[s]: [B,S[s],S[s],3,5+C] (head_dtype);  boxes [B,cap,4] fp32;
  * scores fp32 CLASS-MAJOR [B,C,cap] (element (b,m,c) at (b*C+c)*cap+m; cap % 4 == 0);
  * src_idx [B,cap] (may be NULL when filter == 0); counts [B].
- * anchors host [n_scales][3][2], strides/xyscale host [n_scales]. */
+ * anchors host [n_scales][3][2], strides/xyscale host [n_scales].
+ * Status word: the first int32 of the workspace is zeroed by the call and left nonzero by
+ * the kernel if a workgroup gave up waiting (about a second) for the survivor count of the
+ * segments before it, which a healthy device never does; counts and the compacted outputs
+ * of that call are then invalid.  Callers that synchronise anyway may check it. */
 size_t ymx_decode_workspace_bytes(int B, int n_scales, const int *S /* host */);
 int ymx_decode_filter(const void *const *head /* host array of device ptrs */, int n_scales,
                       const int *S /* host */, int B, int C, int head_dtype,

@@ -249,6 +249,7 @@ def test_benchmark_batch_properties():
     keep = out.keep_idx.cpu().numpy()
     heads = [h.clone() for h in det.forward_heads(x)]
     assert sum(det._plan(B, 416, x.dtype, x.device).sizes) == B
+    det.check_status()
     assert valid.min() > 0 and valid.max() <= 32
     cfg = Y.config
     dec = U.decode_heads([h.reshape(B, h.shape[1], h.shape[2], 3, 5 + C) for h in heads], C, cfg["strides"],

@@ -382,6 +382,16 @@ class Detector(nn.Module):
                                       _lib.ptr(out_valid), _lib.ptr(out_keep), _lib.ptr(part.nms_ws),
                                       part.nms_ws_bytes, _lib.stream()))
 
+    def check_status(self):
+        """Synchronises and raises if any decode+filter launch of this detector's plans left
+        its status word set (a workgroup gave up waiting for the segments before it, which a
+        healthy device never does).  The steady-state path never synchronises, so this is
+        for callers that want the check at a point of their choosing."""
+        words = [part.dec_ws[:4].view(torch.int32) for plan in self._plans.values() for part in plan.parts]
+        if words and bool(torch.cat(words).any().item()):
+            raise RuntimeError("yolo_amd: a decode+filter launch timed out waiting for a predecessor "
+                               "segment (device fault?); its detections are invalid")
+
     def postprocess(self, plan, image_size):
         """decode + filter + combined NMS of the plan's head maps, on the current stream."""
         for part in plan.parts:

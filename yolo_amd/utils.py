@@ -190,7 +190,12 @@ def filter_bboxes(bboxes, scores, score_threshold, image_size):
     _lib.check(L.ymx_filter_boxes(_lib.ptr(bx), _lib.ptr(sc), sb, sn, scs, B, N, C, float(score_threshold),
                                   float(image_size), _lib.ptr(boxes), _lib.ptr(out_cm), _lib.ptr(src_idx),
                                   _lib.ptr(counts), cap, _lib.ptr(ws), ws_bytes, _lib.stream()))
-    mmax = int(counts.max().item()) if B > 0 else 0
+    # one host read for both the largest survivor count and the kernel's status word
+    host = torch.cat([counts.max().reshape(1), ws[:4].view(torch.int32)]).cpu()
+    if int(host[1]) != 0:
+        raise RuntimeError("yolo_amd: filter_bboxes: the compaction kernel timed out waiting for a "
+                           "predecessor segment (device fault?); results are invalid")
+    mmax = int(host[0])
     ar = torch.arange(mmax, device=dev)[None, :]
     valid = ar < counts[:, None]
     b_out = torch.where(valid[..., None], boxes[:, :mmax], torch.zeros((), device=dev))
