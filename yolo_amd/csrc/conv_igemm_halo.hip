@@ -100,6 +100,15 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
         lds_dma16(xrsrc, dst, src);
     };
 
+    // ---- prologue: slab of block 0, weights of tile 0 and W(m0) of tile 1 --------------------
+    // (issued before the fragment geometry below is worked out, which then runs under the loads)
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) issue_slab(0, jj * 8 + wave);
+    lds_dma16(xrsrc, dump, OOB);                           // the spare KB starts out (and stays) zero
+    issue_w(0, 0);
+    issue_w(0, 1);
+    issue_w(1, 0);
+
     // ---- fragment geometry ---------------------------------------------------------------
     // this lane's four pixels (16-pixel blocks j of the wave's 64) and which taps they have
     unsigned fmask[NJ];
@@ -172,13 +181,6 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
         asm volatile("" ::: "memory");
     };
 
-    // ---- prologue: slab of block 0, weights of tile 0 and W(m0) of tile 1 --------------------
-#pragma unroll
-    for (int jj = 0; jj < 6; ++jj) issue_slab(0, jj * 8 + wave);
-    lds_dma16(xrsrc, dump, OOB);                           // the spare KB starts out (and stays) zero
-    issue_w(0, 0);
-    issue_w(0, 1);
-    issue_w(1, 0);
     YMX_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     barrier();
