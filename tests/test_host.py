@@ -54,6 +54,18 @@ def test_argument_validation_without_gpu():
     assert rc == -3
     with pytest.raises(RuntimeError):
         _lib.check(rc)
+    # a program op with a negative tile threshold is rejected, with the op's index in the message
+    assert ctypes.sizeof(_lib.ymx_op) == 18 * 4 + 6 * 8
+    op = _lib.ymx_op()
+    op.kind, op.B, op.H, op.W, op.Cin, op.Cout, op.k, op.stride = 1, 1, 8, 8, 8, 8, 3, 1
+    op.dtype = op.x_dtype = op.out_dtype = _lib.BF16
+    op.x = op.w = op.y = 16
+    op.min_tiles = -1
+    prog = (_lib.ymx_op * 1)(op)
+    rc = L.ymx_run_program(prog, 1, None)
+    assert rc == -1 and b"op 0" in L.ymx_last_error() and b"min_tiles" in L.ymx_last_error()
+    prog[0].kind = 7
+    assert L.ymx_run_program(prog, 1, None) == -1 and b"unknown kind" in L.ymx_last_error()
 
 
 def test_module_interface_matches_reference():
