@@ -12,7 +12,9 @@
 //                  TQ <= 128: 1 x 4 waves of TQ ch x 64 px, TP = 256
 //   K step         32 (one mfma_f32_16x16x32_bf16 deep): LDS rows of 64 B; a 3x3 conv
 //                  with 32 input channels is exactly one tap per step
-//   LDS            NSTAGE (3 or 4) stages x (TP + max(TQ, 64)) rows x 64 B  (72 .. 80 KB)
+//   LDS            NSTAGE (2, 3 or 4) stages x (TP + max(TQ, 64)) rows x 64 B  (72 .. 80 KB;
+//                  40 KB = four workgroups per CU for the two-stage 32-channel tile that
+//                  takes layers of one or two K steps)
 //   pipeline       step s: issue DMA of tile s+NSTAGE-1, MFMAs of tile s, wait for tile
 //                  s+1 (counted vmcnt: the younger pieces may stay in flight), one
 //                  barrier.  A tile therefore has NSTAGE-1 full steps to land.
@@ -235,6 +237,9 @@ int g_dma2_stages = 4;    // pipeline depth of the 32- and 64-channel tiles (3 o
 
 template <typename OT>
 static int launch_dma2_shape(const ConvArgs &a, hipStream_t s) {
+    // A very short K (one or two steps) needs no deep ring: two stages = 40 KB, four
+    // workgroups per CU instead of two to hide the prologue and epilogue latencies.
+    if (a.Cout <= 32 && a.K <= 64 && g_dma2_stages != 3) return launch_dma2_cfg<OT, 32, 2>(a, s);
     if (g_dma2_stages == 4) {
         if (a.Cout <= 32) return launch_dma2_cfg<OT, 32, 4>(a, s);
         if (a.Cout <= 64) return launch_dma2_cfg<OT, 64, 4>(a, s);
