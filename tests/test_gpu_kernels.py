@@ -191,6 +191,11 @@ DMA_SHAPES = [
     (3, 9, 208, 32, 64, 3, False, "mish", True),         # input-slab kernel, rows longer than a tile
     (5, 11, 104, 64, 128, 3, False, "leaky", False),     # input-slab kernel, 64 -> 128
     (2, 30, 7, 32, 40, 3, False, None, True),            # input-slab kernel, short rows, partial channel tile
+    # short K: the two-stage variants (four / three workgroups per CU, 32-channel transpose images)
+    (2, 23, 19, 128, 64, 1, False, "mish", True),        # 64-channel tile, shortcut fetched in two halves
+    (3, 17, 13, 96, 56, 1, False, "leaky", True),        # partial 64 tile, K = 96
+    (2, 21, 22, 64, 24, 1, False, "mish", True),         # 32-channel tile, two K steps, shortcut
+    (1, 40, 9, 8, 64, 3, False, None, False),            # 3x3 with K = 72 on the 64-channel tile
 ]
 
 

@@ -25,10 +25,12 @@ namespace ymx {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int epi_u32x4_t;
 
-template <int NI>
+// HQMAX = channels transposed at a time: 64 (128-byte output runs, 16 KB image per wave) or 32
+// (64-byte runs, 8 KB per wave: for kernels that trade run length for workgroups per CU).
+template <int NI, int HQMAX = 64>
 struct EpiGeom {
     static constexpr int WQ = NI * 16;                       // channels of the wave tile
-    static constexpr int HQ = WQ < 64 ? WQ : 64, NH = WQ / HQ;
+    static constexpr int HQ = WQ < HQMAX ? WQ : HQMAX, NH = WQ / HQ;
     static constexpr int SLOTS = HQ / 4, LPP = SLOTS / 2;    // 16-byte slots per fp32 row; lanes per pixel
     static constexpr int PPI = 64 / LPP, NPASS = 64 / PPI;   // pixels per store instruction; instructions per half
     static constexpr int LDS_BYTES = 64 * HQ * 4;            // private image of one wave
@@ -45,10 +47,10 @@ __device__ __forceinline__ bool epi_res_pre(const ConvArgs &a) {
 
 // Issues the shortcut loads of one half: cbase/pbase are the wave tile's first channel and
 // pixel.  Lanes outside the tensor use an out-of-range offset (zeros, no traffic).
-template <int NI>
+template <int NI, int HQMAX = 64>
 __device__ __forceinline__ void epi_load_res(const ConvArgs &a, int half, int cbase, int pbase, int lane,
-                                             epi_u32x4_t (&r)[EpiGeom<NI>::NPASS]) {
-    typedef EpiGeom<NI> G;
+                                             epi_u32x4_t (&r)[EpiGeom<NI, HQMAX>::NPASS]) {
+    typedef EpiGeom<NI, HQMAX> G;
     const __amdgpu_buffer_rsrc_t rrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void *)a.res, 0, (int)a.res_bytes, 0x00020000);
     const int co = cbase + half * G::HQ + (lane % G::LPP) * 8;
@@ -63,10 +65,10 @@ __device__ __forceinline__ void epi_load_res(const ConvArgs &a, int half, int cb
 
 // rpre[0] must hold the first half's shortcut values if epi_res_pre(a); the second half
 // (128-channel wave tiles) is fetched here, while the first half goes out.
-template <typename OT, int NI, int NJ>
+template <typename OT, int NI, int NJ, int HQMAX = 64>
 __device__ __forceinline__ void epi_run(const ConvArgs &a, f32x4_t (&acc)[NI][NJ], char *tbase, int cbase, int pbase,
-                                        int lane, epi_u32x4_t (&rpre)[EpiGeom<NI>::NH][EpiGeom<NI>::NPASS]) {
-    typedef EpiGeom<NI> G;
+                                        int lane, epi_u32x4_t (&rpre)[EpiGeom<NI, HQMAX>::NH][EpiGeom<NI, HQMAX>::NPASS]) {
+    typedef EpiGeom<NI, HQMAX> G;
     static_assert(NJ == 4, "wave tiles are 64 pixels wide");
     constexpr int HQ = G::HQ, NH = G::NH, SLOTS = G::SLOTS, LPP = G::LPP, PPI = G::PPI, NPASS = G::NPASS;
     OT *__restrict__ y = (OT *)a.y;
@@ -109,8 +111,8 @@ __device__ __forceinline__ void epi_run(const ConvArgs &a, f32x4_t (&acc)[NI][NJ
 #pragma unroll
         for (int half = 0; half < NH; ++half) {
             float sc[8], sh[8];
-            if constexpr (RES && NH == 2) {
-                if (half == 1) epi_load_res<NI>(a, 1, cbase, pbase, lane, rpre[NH - 1]);   // lands during to_lds
+            if constexpr (RES && NH >= 2) {
+                if (half >= 1) epi_load_res<NI, HQMAX>(a, half, cbase, pbase, lane, rpre[half]);   // lands during to_lds
             }
             load_affine(half, sc, sh);
             to_lds(half);

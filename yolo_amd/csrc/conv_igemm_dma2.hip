@@ -34,7 +34,7 @@ namespace ymx {
 
 template <int N> __device__ __forceinline__ void vmcnt_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename OT, int TQ, int NSTAGE>
+template <typename OT, int TQ, int NSTAGE, int EHQ = 64>
 __global__ void __launch_bounds__(256, 2)
 conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     constexpr int WGQ = TQ >= 256 ? 2 : 1, WGP = 4 / WGQ;       // wave grid: channels x pixels
@@ -45,7 +45,7 @@ conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     constexpr int NPIECE = NXI + NWI;
     constexpr int XBYTES = TP * 64, STAGE = (TP + WROWS) * 64;
     constexpr int INFLIGHT = NPIECE * (NSTAGE - 2);             // pieces that may still be in flight at a step's end
-    typedef EpiGeom<NI> Epi;
+    typedef EpiGeom<NI, EHQ> Epi;
     constexpr unsigned OOB = 0x80000000u;
     // (the launcher sizes the dynamic LDS as max(pipeline stages, 4 per-wave transpose images))
 
@@ -100,7 +100,7 @@ conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     const bool res_pre = epi_res_pre(a);
     epi_u32x4_t rpre[Epi::NH][Epi::NPASS];
     if (res_pre && Epi::NH == 1) {
-        epi_load_res<NI>(a, 0, cbase, pbase, lane, rpre[0]);
+        epi_load_res<NI, EHQ>(a, 0, cbase, pbase, lane, rpre[0]);
     } else {
 #pragma unroll
         for (int n = 0; n < Epi::NPASS; ++n) rpre[0][n] = epi_u32x4_t{0u, 0u, 0u, 0u};
@@ -195,7 +195,7 @@ conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
         };
         for (int s = 0; s < nk - 1; ++s) step(s);
         if constexpr (Epi::NH == 2) {
-            if (res_pre) epi_load_res<NI>(a, 0, cbase, pbase, lane, rpre[0]);   // older than the last step's pieces
+            if (res_pre) epi_load_res<NI, EHQ>(a, 0, cbase, pbase, lane, rpre[0]);   // older than the last step's pieces
         }
         step(nk - 1);
     }
@@ -204,18 +204,18 @@ conv_igemm_dma2_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     YMX_STAMP(3);
 
     // ---- epilogue: per-wave transpose through LDS (conv_epilogue.h) --------------------
-    epi_run<OT, NI, NJ>(a, acc, smem + wave * Epi::LDS_BYTES, cbase, pbase, lane, rpre);
+    epi_run<OT, NI, NJ, EHQ>(a, acc, smem + wave * Epi::LDS_BYTES, cbase, pbase, lane, rpre);
     YMX_STAMP_END(5);
 }
 
-template <typename OT, int TQ, int NSTAGE>
+template <typename OT, int TQ, int NSTAGE, int EHQ = 64>
 static int launch_dma2_cfg(const ConvArgs &a, hipStream_t s) {
     constexpr int TP = TQ >= 256 ? 128 : 256;
     constexpr int WROWS = TQ < 64 ? 64 : TQ;
-    constexpr int HQ = (TQ >= 256 ? 128 : TQ) < 64 ? TQ : 64;
-    constexpr int PIPE = NSTAGE * (TP + WROWS) * 64, EPI = 4 * 64 * HQ * 4;
+    constexpr int WQ = TQ >= 256 ? 128 : TQ;
+    constexpr int PIPE = NSTAGE * (TP + WROWS) * 64, EPI = 4 * EpiGeom<WQ / 16, EHQ>::LDS_BYTES;
     constexpr int LDS = PIPE > EPI ? PIPE : EPI;
-    auto kern = conv_igemm_dma2_kernel<OT, TQ, NSTAGE>;
+    auto kern = conv_igemm_dma2_kernel<OT, TQ, NSTAGE, EHQ>;
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -237,9 +237,15 @@ int g_dma2_stages = 4;    // pipeline depth of the 32- and 64-channel tiles (3 o
 
 template <typename OT>
 static int launch_dma2_shape(const ConvArgs &a, hipStream_t s) {
-    // A very short K (one or two steps) needs no deep ring: two stages = 40 KB, four
-    // workgroups per CU instead of two to hide the prologue and epilogue latencies.
-    if (a.Cout <= 32 && a.K <= 64 && g_dma2_stages != 3) return launch_dma2_cfg<OT, 32, 2>(a, s);
+    // A short K (up to four steps) needs no deep ring: two stages = 40 KB of LDS, and the
+    // workgroups per CU that buys (four of the 32-channel tile, three of the 64-channel one,
+    // whose transpose images are then 32 channels wide) hide the prologue and epilogue
+    // latencies that dominate such layers.  Measured: 1x1 64->32 @208^2 -25 %, 1x1 128->64
+    // @104^2 -13 %; no gain for the nine-step stride-2 3x3 32->64, which keeps four stages.
+    if (g_dma2_stages != 3) {
+        if (a.Cout <= 32 && a.K <= 64) return launch_dma2_cfg<OT, 32, 2>(a, s);
+        if (a.Cout > 32 && a.Cout <= 64 && a.K <= 128) return launch_dma2_cfg<OT, 64, 2, 32>(a, s);
+    }
     if (g_dma2_stages == 4) {
         if (a.Cout <= 32) return launch_dma2_cfg<OT, 32, 4>(a, s);
         if (a.Cout <= 64) return launch_dma2_cfg<OT, 64, 4>(a, s);
