@@ -40,29 +40,26 @@ PEAK_HBM_GBS = 8000.0          # HBM3E peak (spec)
 
 
 def conv_kernel_name(op):
+    """Label of the kernel the library launches for a program op (asked of the library itself)."""
     if op.kind != 1:
         return "upsample2x_concat"
+    from yolo_amd import _lib
+    fam = _lib.lib().ymx_conv_kernel_label(_lib.ctypes.byref(op))
+    if fam is None:
+        raise RuntimeError("bench: " + _lib.lib().ymx_last_error().decode())
+    fam = fam.decode()
     bf16 = op.dtype == 1
-    if (op.Cin % 8 if bf16 else op.Cin % 4):
-        return "conv_first_rows" if (op.Cin == 3 and op.k == 3 and op.stride == 1 and op.Cout == 32) else "conv_direct"
-    # mirrors the choice in yolo_amd/csrc/api.hip (default options)
-    oh = op.H if op.stride == 1 else (op.H + 1 - op.k) // 2 + 1
-    ow = op.W if op.stride == 1 else (op.W + 1 - op.k) // 2 + 1
-    ptiles = (op.B * oh * ow + 255) // 256
-    if bf16 and op.Cout > 128 and ptiles * ((op.Cout + 255) // 256) >= 160:
-        if op.k == 3 and op.stride == 1 and op.Cin % 64 == 0 and op.W <= 59:
-            return "conv_igemm_halo_bf16_256x256"     # 3x3: input pixels resident in LDS across the taps
-        if op.k == 1 and ptiles * ((op.Cout + 255) // 256) >= 600:
-            return "conv_igemm_dma4_bf16_256x256"     # long 1x1 layers: phase-staggered wave groups
-        return "conv_igemm_dma_bf16_256x256"          # two-stage large-tile LDS-DMA kernel
-    if bf16 and op.Cout <= 128 and ptiles >= 160:
-        if op.k == 3 and op.stride == 1 and ((op.Cin == 32 and op.Cout <= 64 and op.W <= 400) or
-                                             (op.Cin == 64 and op.Cout <= 128 and op.W <= 110)):
-            return "conv_igemm_slab2_bf16_cin%d" % op.Cin    # narrow 3x3: input slab resident in LDS
-        tq = 32 if op.Cout <= 32 else (64 if op.Cout <= 64 else 128)
-        return "conv_igemm_dma2_bf16_%dx256" % tq     # narrow-layer LDS-DMA kernel, several workgroups per CU
-    tile = "256x32" if op.Cout <= 32 else ("256x64" if op.Cout <= 64 else "128x128")
-    return "conv_igemm_%s_%s" % ("bf16" if bf16 else "f32", tile)
+    if fam in ("halo", "dma", "dma4"):
+        return "conv_igemm_%s_bf16_256x256" % fam
+    if fam == "slab2":
+        return "conv_igemm_slab2_bf16_cin%d" % op.Cin
+    if fam == "dma2":
+        tq = 32 if op.Cout <= 32 else (64 if op.Cout <= 64 else (128 if op.Cout <= 128 else 256))
+        return "conv_igemm_dma2_bf16_%dx256" % tq
+    if fam == "igemm":
+        tile = "256x32" if op.Cout <= 32 else ("256x64" if op.Cout <= 64 else "128x128")
+        return "conv_igemm_%s_%s" % ("bf16" if bf16 else "f32", tile)
+    return "conv_" + fam
 
 
 # bench label -> device kernel name in the rocprofv3 summaries under profiles/

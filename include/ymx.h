@@ -41,19 +41,22 @@ enum {
 int ymx_version(void);
 const char *ymx_last_error(void);
 
-/* Process-wide tuning knobs (no counterpart in the reference).  "dma_min_tiles": the
- * fewest 256x256 output tiles for which a bf16 convolution with more than 128 output
- * channels runs on the large-tile LDS-DMA kernel instead of the 128x128 kernel
- * (default 160; 0 forces it, a huge value disables it).  "dma_variant": which large-tile
- * kernel wide layers use (5, the default: chosen per shape -- input pixels resident in
- * LDS for 3x3 stride 1, phase-staggered wave groups for long 1x1 layers, the two-stage
- * kernel otherwise; 1: two-stage 256x256 everywhere; 2: 256x128 tile, two workgroups per
- * CU; 4: phase-staggered wave groups everywhere).  "dma_stages":
- * pipeline depth (3 or 4, default 4) of the 32- and 64-channel narrow-layer tiles.  "dma_narrow": bf16 layers of <= 128 output channels
- * with at least dma_min_tiles 256-pixel tiles run on the LDS-DMA kernels (2, the default:
- * with the input-resident kernel for 3x3 stride 1 and 32 or 64 input channels; 1: without
- * it) or on the register-staged kernel (0).  All kernels add the K terms in the same order: results do
- * not depend on these options. */
+/* Tuning knobs (no counterpart in the reference).  They are PER CALLING THREAD: a thread
+ * that sets one changes only its own later calls, every thread starts from the defaults, and
+ * the library keeps no other mutable state besides the thread-local error string (kernel
+ * attributes it sets once per device are idempotent).  "dma_min_tiles": the fewest 256x256
+ * output tiles for which a bf16 convolution with more than 128 output channels runs on the
+ * large-tile LDS-DMA kernel instead of the 128x128 kernel (default 160; 0 forces it, a huge
+ * value disables it; ymx_op.min_tiles overrides it per op).  "dma_variant": which large-tile
+ * kernel wide layers use (5, the default: chosen per shape -- input pixels resident in LDS
+ * for 3x3 stride 1, phase-staggered wave groups for long 1x1 layers, the two-stage kernel
+ * otherwise; 1: two-stage 256x256 everywhere; 2: 256x128 tile, two workgroups per CU; 4:
+ * phase-staggered wave groups everywhere).  "dma_stages": pipeline depth (3 or 4, default
+ * 4) of the 32- and 64-channel narrow-layer tiles.  "dma_narrow": bf16 layers of <= 128
+ * output channels with at least dma_min_tiles 256-pixel tiles run on the LDS-DMA kernels
+ * (2, the default: with the input-resident kernel for 3x3 stride 1 and 32 or 64 input
+ * channels; 1: without it) or on the register-staged kernel (0).  All kernels add the K
+ * terms in the same order: results do not depend on these options. */
 int ymx_set_option(const char *name, long long value);
 
 /* ---- convolution block ------------------------------------------------------
@@ -125,6 +128,13 @@ typedef struct ymx_op {
     void *y;
 } ymx_op;
 int ymx_run_program(const ymx_op *ops /* host */, int n_ops, void *stream);
+
+/* Diagnostic (no counterpart in the reference): the kernel family ymx_run_program would
+ * launch for a convolution op with the calling thread's options -- "halo", "dma", "dma4",
+ * "dma2", "slab2", "igemm", "first_rows" or "direct" (a static string) -- or NULL with
+ * ymx_last_error() set when the op is invalid.  Nothing is launched.  Benchmarks use it to
+ * attribute measured launch times to kernels without mirroring the selection rules. */
+const char *ymx_conv_kernel_label(const ymx_op *op /* host */);
 
 /* ---- decode (+ score filter) ------------------------------------------------
  * Replaces decode / decode_predict (utils.py:107-126, 133-140) for all scales at

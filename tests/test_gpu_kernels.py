@@ -196,6 +196,12 @@ DMA_SHAPES = [
     (3, 17, 13, 96, 56, 1, False, "leaky", True),        # partial 64 tile, K = 96
     (2, 21, 22, 64, 24, 1, False, "mish", True),         # 32-channel tile, two K steps, shortcut
     (1, 40, 9, 8, 64, 3, False, None, False),            # 3x3 with K = 72 on the 64-channel tile
+    # rows at and beyond the input-slab kernel's LDS limit (image sides 686 ... 800 reach these widths)
+    (1, 3, 343, 32, 64, 3, False, "mish", True),         # longest 32-channel row the slab kernel takes (80 KB)
+    (1, 2, 352, 32, 64, 3, False, "mish", True),         # one past it: the streaming kernel
+    (1, 2, 400, 32, 64, 3, False, "leaky", False),
+    (1, 3, 123, 64, 128, 3, False, "mish", True),        # longest 64-channel row of the slab kernel
+    (1, 3, 124, 64, 128, 3, False, "mish", False),
 ]
 
 

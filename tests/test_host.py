@@ -23,7 +23,7 @@ def _declared_symbols():
 def test_library_exports_every_declared_symbol():
     from yolo_amd import _lib
     declared = _declared_symbols()
-    assert len(declared) >= 17
+    assert len(declared) >= 20
     assert sorted(_lib.SIGNATURES) == declared          # the binding covers the header exactly
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
@@ -150,17 +150,18 @@ import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %(root)r)
 from yolo_amd import dist as D
 from yolo_amd.utils import Detections
-dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+WORLD = %(world)d
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=WORLD)
 rank = dist.get_rank()
 T = 4
 ok = True
-for GB in (5, 4, 1):                      # uneven shards, even shards, a rank with no image
+for GB in (2 * WORLD + 3, 4 * WORLD, 1):  # uneven shards, even shards, ranks with no image
     g = torch.Generator().manual_seed(7 + GB)
     full = Detections(torch.rand(GB, T, 4, generator=g), torch.rand(GB, T, generator=g),
                       torch.randint(0, 80, (GB, T), generator=g).float(),
                       torch.randint(0, T + 1, (GB,), generator=g, dtype=torch.int32),
                       torch.randint(-1, 999, (GB, T), generator=g, dtype=torch.int32))
-    s, c = D.shard_range(GB, rank, 2)
+    s, c = D.shard_range(GB, rank, WORLD)
     mine = Detections(*[t[s:s + c].clone() for t in full], full.keep_idx[s:s + c].clone())
     got = D.all_gather_detections(mine, GB)
     ok = ok and all(torch.equal(a, b) for a, b in zip(tuple(full) + (full.keep_idx,), tuple(got) + (got.keep_idx,)))
@@ -169,13 +170,103 @@ sys.exit(0 if ok else 3)
 """
 
 
-def test_all_gather_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_all_gather_gloo(tmp_path, world):
+    """Shard -> pack -> all-gather -> unpack over gloo at every world size the benchmark is
+    launched with: the gathered detections equal the unsharded ones bit for bit."""
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER % {"root": ROOT, "port": port})
-    procs = [subprocess.Popen([sys.executable, str(script), str(r)]) for r in range(2)]
-    codes = [p.wait(timeout=120) for p in procs]
-    assert codes == [0, 0]
+    script.write_text(_WORKER % {"root": ROOT, "port": port, "world": world})
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], env=env) for r in range(world)]
+    codes = [p.wait(timeout=300) for p in procs]
+    assert codes == [0] * world
+
+
+def _conv_op(B, H, W, cin, cout, k, stride=1, min_tiles=0):
+    from yolo_amd import _lib
+    op = _lib.ymx_op()
+    op.kind, op.B, op.H, op.W, op.Cin, op.Cout, op.k, op.stride = 1, B, H, W, cin, cout, k, stride
+    op.dtype = op.x_dtype = op.out_dtype = _lib.BF16
+    op.x = op.w = op.y = 256          # never dereferenced: the label call validates and selects only
+    op.min_tiles = min_tiles
+    return op
+
+
+def _label(op):
+    from yolo_amd import _lib
+    r = _lib.lib().ymx_conv_kernel_label(ctypes.byref(op))
+    return None if r is None else r.decode()
+
+
+def test_kernel_selection_labels():
+    """Which kernel family a layer is routed to, asked of the library (no GPU needed)."""
+    assert _label(_conv_op(64, 52, 52, 512, 1024, 3)) == "halo"
+    assert _label(_conv_op(64, 76, 76, 512, 1024, 3)) == "dma"        # rows too long for two resident slabs
+    assert _label(_conv_op(64, 52, 52, 1024, 512, 1)) == "dma4"
+    assert _label(_conv_op(64, 26, 26, 512, 1024, 3, stride=2)) == "dma"
+    assert _label(_conv_op(1, 13, 13, 512, 1024, 3)) == "igemm"       # too few tiles for the large-tile kernels
+    assert _label(_conv_op(1, 13, 13, 512, 1024, 3, min_tiles=1)) == "halo"
+    assert _label(_conv_op(64, 208, 208, 32, 64, 3)) == "slab2"
+    assert _label(_conv_op(64, 208, 208, 64, 32, 1)) == "dma2"
+    # the input-slab kernel is chosen by its real LDS need: 32-channel rows up to 343 pixels,
+    # 64-channel rows up to 123; longer rows fall through to the streaming kernel
+    assert _label(_conv_op(16, 343, 343, 32, 64, 3)) == "slab2"
+    for w in (344, 352, 368, 384, 400):                                 # image sides 688 ... 800
+        assert _label(_conv_op(16, w, w, 32, 64, 3)) == "dma2", w
+    assert _label(_conv_op(16, 123, 123, 64, 128, 3)) == "slab2"
+    assert _label(_conv_op(16, 124, 124, 64, 128, 3)) == "dma2"
+    from yolo_amd import _lib
+    bad = _conv_op(1, 8, 8, 8, 8, 4)
+    assert _label(bad) is None and b"kernel size" in _lib.lib().ymx_last_error()
+    first = _conv_op(2, 64, 64, 3, 32, 3)
+    first.x_dtype = _lib.F32
+    assert _label(first) == "first_rows"
+
+
+def test_options_are_per_thread():
+    """ymx_set_option changes the calling thread only: two threads holding different options
+    select different kernels for the same op, repeatedly and concurrently, and a fresh thread
+    sees the defaults."""
+    import threading
+    from yolo_amd import _lib
+    L = _lib.lib()
+    op_args = (64, 52, 52, 512, 1024, 3)
+    want = {1: "dma", 4: "dma4", 5: "halo"}
+    errors = []
+    start = threading.Barrier(3)
+
+    def worker(variant):
+        try:
+            _lib.check(L.ymx_set_option(b"dma_variant", variant))
+            start.wait()
+            for _ in range(2000):
+                got = _label(_conv_op(*op_args))
+                if got != want[variant]:
+                    errors.append((variant, got))
+                    return
+        except Exception as e:          # noqa: BLE001 - reported through the list
+            errors.append((variant, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(v,)) for v in (1, 4, 5)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    # this thread never set anything: defaults, whatever the workers did
+    assert _label(_conv_op(*op_args)) == "halo"
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(_label(_conv_op(*op_args))))
+    t.start(); t.join()
+    assert seen == ["halo"]
+    # min_tiles too: a thread that disables the large-tile kernels does not affect this one
+    def disable():
+        _lib.check(L.ymx_set_option(b"dma_min_tiles", 1 << 40))
+        seen.append(_label(_conv_op(*op_args)))
+    t = threading.Thread(target=disable)
+    t.start(); t.join()
+    assert seen[-1] == "igemm" and _label(_conv_op(*op_args)) == "halo"

@@ -36,6 +36,7 @@ SIGNATURES = {
     "ymx_conv2d_fused_ex": (_i, [_vp] * 6 + [_i] * 14 + [_vp]),
     "ymx_upsample2x_concat": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ymx_run_program": (_i, [ctypes.POINTER(ymx_op), _i, _vp]),
+    "ymx_conv_kernel_label": (ctypes.c_char_p, [ctypes.POINTER(ymx_op)]),
     "ymx_decode_workspace_bytes": (_sz, [_i, _i, ctypes.POINTER(_i)]),
     "ymx_decode_filter": (_i, [ctypes.POINTER(_vp), _i, ctypes.POINTER(_i), _i, _i, _i,
                                ctypes.POINTER(_f), ctypes.POINTER(_f), ctypes.POINTER(_f),
@@ -106,5 +107,20 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream(ref=None):
+    """The current HIP stream of ref's device (of the current device without ref)."""
+    dev = None if ref is None else ref.device
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def launch(name, ref, *args):
+    """Call the launching entry point ``name`` with ``args`` plus, as its last argument, the
+    current stream of the device that tensor ``ref`` lives on, with that device current
+    (kernel attributes and launches are per device), and raise on a negative return code."""
+    fn = getattr(lib(), name)
+    dev = ref.device
+    if dev.index is None or dev.index == torch.cuda.current_device():
+        check(fn(*args, stream(ref)))
+    else:
+        with torch.cuda.device(dev):
+            check(fn(*args, stream(ref)))

@@ -1,6 +1,7 @@
 // extern "C" surface of libymx: argument validation, kernel selection, error strings.
 // No device memory is allocated or freed here and nothing synchronises; the only
 // runtime calls besides launches are hipMemsetAsync on caller-provided workspace.
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -33,25 +34,55 @@ int check_launch(const char *what) {
 
 static bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
+// Tuning options (ymx_set_option) are per calling thread: a thread that changes one affects
+// only its own later calls, so concurrent callers never see each other's settings and
+// nothing here needs a lock.  Every thread starts from the defaults.
+struct Tuning {
+    long long variant = 5;      // wide layers: 5 = resident-slab kernel for 3x3 stride 1, phase-staggered kernel for
+                                // long 1x1 layers, the two-stage 256x256 kernel otherwise; 1, 2, 4: see ymx_set_option
+    long long narrow = 2;       // layers of <= 128 output channels: 2 = LDS-DMA kernels (resident input slab for
+                                // 3x3 stride 1 with 32/64 input channels), 1 = without the slab kernel, 0 = register-staged
+    long long min_tiles = -1;   // < 0: the default below
+};
+static thread_local Tuning t_opt;
+thread_local int g_dma2_stages = 4;    // pipeline depth of the 32- and 64-channel narrow tiles (3 or 4)
+
 // Fewest 256x256 tiles for which the large-tile kernel is chosen (one workgroup per CU,
-// 256 CUs).  YMX_DMA_MIN_TILES overrides it for experiments (a huge value disables the
-// kernel, 0 forces it).
-static long long g_dma_variant = 5;      // wide layers: 5 = resident-slab kernel for 3x3 stride 1 and the two-stage 256x256 kernel otherwise; 1-4: see ymx_set_option
-static long long g_dma_narrow = 2;       // layers of <= 128 output channels: 2 = LDS-DMA kernels (resident input slab for
-                                         // 3x3 stride 1 with 32/64 input channels), 1 = without the slab kernel, 0 = register-staged
-static long long g_dma_min_tiles = -1;
-static long long dma_min_tiles() {
-    if (g_dma_min_tiles < 0) {
+// 256 CUs).  YMX_DMA_MIN_TILES, read once per process, overrides the default of 160 for
+// experiments (a huge value disables the kernel, 0 forces it).
+static long long default_min_tiles() {
+    static const long long v = [] {
         const char *e = getenv("YMX_DMA_MIN_TILES");
-        g_dma_min_tiles = e ? atoll(e) : 160;
+        return e ? atoll(e) : 160ll;
+    }();
+    return v;
+}
+static long long dma_min_tiles() { return t_opt.min_tiles >= 0 ? t_opt.min_tiles : default_min_tiles(); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel.  The
+// caller keeps one LdsReserve per kernel instantiation; bit d records that device d has
+// been set up.  Setting the attribute twice is harmless, so two threads racing here are too.
+int reserve_lds(LdsReserve &st, const void *kern, int bytes, const char *what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(YMX_ELAUNCH, "%s: no current device", what);
     }
-    return g_dma_min_tiles;
+    const bool tracked = dev >= 0 && dev < 64;
+    if (tracked && ((st.done.load(std::memory_order_acquire) >> dev) & 1ull)) return YMX_OK;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(YMX_ELAUNCH, "%s: cannot reserve %d bytes of LDS", what, bytes);
+    }
+    if (tracked) st.done.fetch_or(1ull << dev, std::memory_order_release);
+    return YMX_OK;
 }
 
 static int conv_impl(const void *x, const void *w, const void *scale, const void *shift,
                      const void *residual, void *y, int B, int H, int W, int Cin, int Cout, int k,
                      int stride, int act, int dtype, int x_dtype, int out_dtype, int x_ld, int res_ld,
-                     int y_ld, hipStream_t s, int op_min_tiles = 0) {
+                     int y_ld, hipStream_t s, int op_min_tiles = 0, const char **label = nullptr) {
+    // label != nullptr: validate and select only; *label names the kernel family, nothing is launched
     if (!x || !w || !y) return fail(YMX_EARG, "conv2d: null x, w or y");
     if (op_min_tiles < 0) return fail(YMX_EARG, "conv2d: negative min_tiles");
     const long long min_tiles = op_min_tiles > 0 ? op_min_tiles : dma_min_tiles();
@@ -79,8 +110,9 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
     a.y_ld = y_ld > 0 ? y_ld : Cout;
     if (a.x_ld < Cin || a.y_ld < Cout || a.res_ld < Cout) return fail(YMX_EARG, "conv2d: pixel stride below channel count");
     const long long P = (long long)B * a.OH * a.OW;
-    if (P > 0x7fffffffLL || (long long)B * H * W * a.x_ld > 0x7fffffffLL || P * a.y_ld > 0x7fffffffffLL)
-        return fail(YMX_EUNSUPPORTED, "conv2d: tensor exceeds 2^31 elements");
+    // pixel counts and input offsets are 32-bit in the kernels; output offsets are size_t
+    if (P > 0x7fffffffLL || (long long)B * H * W * a.x_ld > 0x7fffffffLL)
+        return fail(YMX_EUNSUPPORTED, "conv2d: more than 2^31 output pixels or input elements");
     a.P = (int)P;
     a.K = k * k * Cin;
     set_fastdiv((unsigned)(a.OH * a.OW), a.ohw_m, a.ohw_s);
@@ -112,26 +144,29 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         if (dtype == YMX_BF16 && Cout > 128) {
             const long long tiles = ((long long)(a.P + 255) / 256) * ((Cout + 255) / 256);
             if (tiles >= min_tiles) {
-                switch (g_dma_variant) {
+                // 3x3 stride 1: input pixels resident in LDS across the taps; long 1x1 layers
+                // (several rounds of tiles): phase-staggered wave groups; the two-stage kernel
+                // for the rest (measured per shape class on MI355X)
+                int which = (int)t_opt.variant;
+                if (which == 5) which = conv_halo_eligible(a) ? 5 : ((k == 1 && tiles >= 600) ? 4 : 1);
+                static const char *const names[6] = {"", "dma", "dma2", "", "dma4", "halo"};
+                if (label) { *label = names[which]; return YMX_OK; }
+                switch (which) {
                 case 1: return launch_conv_igemm_dma(a, s);
                 case 2: return launch_conv_igemm_dma2(a, s);
                 case 4: return launch_conv_igemm_dma4(a, s);
-                default:
-                    // 3x3 stride 1: input pixels resident in LDS across the taps; long 1x1
-                    // layers (several rounds of tiles): phase-staggered wave groups; the
-                    // two-stage kernel for the rest (measured per shape class on MI355X)
-                    if (conv_halo_eligible(a)) return launch_conv_igemm_halo(a, s);
-                    if (k == 1 && tiles >= 600) return launch_conv_igemm_dma4(a, s);
-                    return launch_conv_igemm_dma(a, s);
+                default: return launch_conv_igemm_halo(a, s);
                 }
             }
         }
         // Narrow layers (the first backbone stages): memory-bound; the several-workgroups-
         // per-CU LDS-DMA kernel with channel tiles of 32/64/128.
-        if (dtype == YMX_BF16 && Cout <= 128 && g_dma_narrow && (a.P + 255) / 256 >= min_tiles) {
-            if (g_dma_narrow == 2 && conv_slab2_eligible(a)) return launch_conv_igemm_slab2(a, s);
-            return launch_conv_igemm_dma2(a, s);
+        if (dtype == YMX_BF16 && Cout <= 128 && t_opt.narrow && (a.P + 255) / 256 >= min_tiles) {
+            const bool slab = t_opt.narrow == 2 && conv_slab2_eligible(a);
+            if (label) { *label = slab ? "slab2" : "dma2"; return YMX_OK; }
+            return slab ? launch_conv_igemm_slab2(a, s) : launch_conv_igemm_dma2(a, s);
         }
+        if (label) { *label = "igemm"; return YMX_OK; }
         return launch_conv_igemm(a, s);
     }
     if (!aligned16(y)) return fail(YMX_EARG, "conv2d: y must be 16-byte aligned");
@@ -142,6 +177,7 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         const long long xb = (((long long)B * H * W - 1) * a.x_ld + Cin) * (x_dtype == YMX_BF16 ? 2 : 4);
         a.x_bytes = (xb <= 0x80000000LL && aligned16(x)) ? (unsigned)xb : 0u;
     }
+    if (label) { *label = conv_first_rows_eligible(a) ? "first_rows" : "direct"; return YMX_OK; }
     return launch_conv_direct(a, s);
 }
 
@@ -157,12 +193,12 @@ int ymx_set_option(const char *name, long long value) {
     if (!name) return fail(YMX_EARG, "set_option: null name");
     if (!strcmp(name, "dma_min_tiles")) {
         if (value < 0) return fail(YMX_EARG, "set_option: dma_min_tiles must be >= 0");
-        g_dma_min_tiles = value;
+        t_opt.min_tiles = value;
         return YMX_OK;
     }
     if (!strcmp(name, "dma_variant")) {
         if (value < 1 || value > 5 || value == 3) return fail(YMX_EARG, "set_option: dma_variant must be 1, 2, 4 or 5");
-        g_dma_variant = value;
+        t_opt.variant = value;
         return YMX_OK;
     }
     if (!strcmp(name, "dma_stages")) {
@@ -172,7 +208,7 @@ int ymx_set_option(const char *name, long long value) {
     }
     if (!strcmp(name, "dma_narrow")) {
         if (value < 0 || value > 2) return fail(YMX_EARG, "set_option: dma_narrow must be 0, 1 or 2");
-        g_dma_narrow = value;
+        t_opt.narrow = value;
         return YMX_OK;
     }
     return fail(YMX_EARG, "set_option: unknown option '%s'", name);
@@ -237,6 +273,15 @@ int ymx_run_program(const ymx_op *ops, int n_ops, void *stream) {
         }
     }
     return YMX_OK;
+}
+
+const char *ymx_conv_kernel_label(const ymx_op *op) {
+    if (!op || op->kind != 1) { fail(YMX_EARG, "conv_kernel_label: not a convolution op"); return nullptr; }
+    const ymx_op &o = *op;
+    const char *label = nullptr;
+    const int rc = conv_impl(o.x, o.w, o.scale, o.shift, o.residual, o.y, o.B, o.H, o.W, o.Cin, o.Cout, o.k, o.stride,
+                             o.act, o.dtype, o.x_dtype, o.out_dtype, o.x_ld, o.res_ld, o.y_ld, nullptr, o.min_tiles, &label);
+    return rc == YMX_OK ? label : nullptr;
 }
 
 // workspace layout of the decode/filter calls: [err:4 int][ticket: B int, padded to 16 B][state: B*nseg u64]

@@ -1,6 +1,7 @@
 // Internal declarations shared by the kernel translation units and the C ABI.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/ymx.h"
@@ -10,6 +11,10 @@ namespace ymx {
 // ---- error reporting (thread-local message behind ymx_last_error) ------------
 int fail(int code, const char *fmt, ...);
 int check_launch(const char *what);
+
+// ---- per-device kernel attributes ---------------------------------------------
+struct LdsReserve { std::atomic<unsigned long long> done{0}; };
+int reserve_lds(LdsReserve &st, const void *kern, int bytes, const char *what);
 
 // ---- element helpers ---------------------------------------------------------
 typedef uint16_t bf16_t;   // raw bfloat16 bits in memory
@@ -200,7 +205,8 @@ int launch_conv_igemm_halo(const ConvArgs &a, hipStream_t s);
 bool conv_halo_eligible(const ConvArgs &a);
 int launch_conv_igemm_slab2(const ConvArgs &a, hipStream_t s);
 bool conv_slab2_eligible(const ConvArgs &a);
-extern int g_dma2_stages;
+extern thread_local int g_dma2_stages;     // per calling thread, like every tuning option
+bool conv_first_rows_eligible(const ConvArgs &a);
 int launch_conv_direct(const ConvArgs &a, hipStream_t s);
 int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype,
                         hipStream_t s);

@@ -275,8 +275,13 @@ static bool first_layer_shape(const ConvArgs &a) {
            a.out_dtype == YMX_BF16 && a.res == nullptr && (a.y_ld & 7) == 0;
 }
 
+// The network's first layer on a dense fp32 image: the row-run kernel above.
+bool conv_first_rows_eligible(const ConvArgs &a) {
+    return first_layer_shape(a) && a.x_dtype == YMX_F32 && a.x_ld == 3 && a.x_bytes != 0;
+}
+
 int launch_conv_direct(const ConvArgs &a, hipStream_t s) {
-    if (first_layer_shape(a) && a.x_dtype == YMX_F32 && a.x_ld == 3 && a.x_bytes != 0) {
+    if (conv_first_rows_eligible(a)) {
         const int cpr = (a.OW + 63) / 64;
         const int nchunk = a.B * a.OH * cpr;
         const int blocks = (nchunk + 3) / 4 < 256 * 8 ? (nchunk + 3) / 4 : 256 * 8;

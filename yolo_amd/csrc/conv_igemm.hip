@@ -224,14 +224,8 @@ static int launch_cfg(const ConvArgs &a, hipStream_t s) {
     constexpr int KCH = 16 / (int)sizeof(T), BK = 8 * KCH;
     constexpr int LDS = 2 * (TP + TQ) * 128;
     auto kern = conv_igemm_kernel<T, OT, TP, TQ, WGP>;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(YMX_ELAUNCH, "conv_igemm: cannot reserve %d bytes of LDS", LDS);
-        }
-        configured = true;
-    }
+    static LdsReserve reserved;        // one per kernel instantiation; remembers the devices already set up
+    if (const int rc = reserve_lds(reserved, (const void *)kern, LDS, "conv_igemm")) return rc;
     const int ntile_p = (a.P + TP - 1) / TP;
     const int ntile_q = (a.Cout + TQ - 1) / TQ;
     const int nk = (a.K + BK - 1) / BK;

@@ -163,14 +163,8 @@ template <typename OT, int TQ>
 static int launch_dma_cfg(const ConvArgs &a, hipStream_t s) {
     constexpr int LDS = 2 * (256 + TQ) * 128;
     auto kern = conv_igemm_dma_kernel<OT, TQ>;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(YMX_ELAUNCH, "conv_igemm_dma: cannot reserve %d bytes of LDS", LDS);
-        }
-        configured = true;
-    }
+    static LdsReserve reserved;        // one per kernel instantiation; remembers the devices already set up
+    if (const int rc = reserve_lds(reserved, (const void *)kern, LDS, "conv_igemm_dma")) return rc;
     const int ntile_p = (a.P + 255) / 256;
     const int ntile_q = (a.Cout + TQ - 1) / TQ;
     const int nk = (a.K + 63) / 64;

@@ -216,14 +216,8 @@ static int launch_dma2_cfg(const ConvArgs &a, hipStream_t s) {
     constexpr int PIPE = NSTAGE * (TP + WROWS) * 64, EPI = 4 * EpiGeom<WQ / 16, EHQ>::LDS_BYTES;
     constexpr int LDS = PIPE > EPI ? PIPE : EPI;
     auto kern = conv_igemm_dma2_kernel<OT, TQ, NSTAGE, EHQ>;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(YMX_ELAUNCH, "conv_igemm_dma2: cannot reserve %d bytes of LDS", LDS);
-        }
-        configured = true;
-    }
+    static LdsReserve reserved;        // one per kernel instantiation; remembers the devices already set up
+    if (const int rc = reserve_lds(reserved, (const void *)kern, LDS, "conv_igemm_dma2")) return rc;
     const int ntile_p = (a.P + TP - 1) / TP;
     const int ntile_q = (a.Cout + TQ - 1) / TQ;
     const int nk = (a.K + 31) / 32;
@@ -233,7 +227,6 @@ static int launch_dma2_cfg(const ConvArgs &a, hipStream_t s) {
     return check_launch("conv_igemm_dma2");
 }
 
-int g_dma2_stages = 4;    // pipeline depth of the 32- and 64-channel tiles (3 or 4)
 
 template <typename OT>
 static int launch_dma2_shape(const ConvArgs &a, hipStream_t s) {

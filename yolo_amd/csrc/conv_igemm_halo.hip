@@ -260,14 +260,8 @@ static int launch_halo_cfg(const ConvArgs &a, hipStream_t s) {
     int lds = 2 * npieces * 1024 + 4 * 128 * 128 + 1024;
     if (lds < 8 * EpiGeom<8>::LDS_BYTES) lds = 8 * EpiGeom<8>::LDS_BYTES;      // the epilogue's transpose images
     auto kern = conv_igemm_halo_kernel<OT>;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(YMX_ELAUNCH, "conv_igemm_halo: cannot reserve 160 KB of LDS");
-        }
-        configured = true;
-    }
+    static LdsReserve reserved;        // one per kernel instantiation; remembers the devices already set up
+    if (const int rc = reserve_lds(reserved, (const void *)kern, 160 * 1024, "conv_igemm_halo")) return rc;
     const int ntile_p = (a.P + 255) / 256;
     const int ntile_q = (a.Cout + 255) / 256;
     const long long grid = (long long)ntile_p * ntile_q;

@@ -152,31 +152,35 @@ conv_igemm_slab2_kernel(const ConvArgs a, const int npieces) {
 
 // Shapes this kernel takes: 3x3 stride 1, 32 input channels into <= 64 output channels or
 // 64 into <= 128, rows short enough for the slab of two workgroups to share a CU's LDS.
+// LDS bytes of one workgroup: the input slab (tile pixels plus a row and a pixel on either
+// side, in 1 KB DMA pieces), the weight ring, one zero row; never less than the epilogue's
+// transpose images.  Two workgroups share a CU, so 80 KB is the limit.
+static constexpr int SLAB2_LDS_MAX = 80 * 1024;
+static int slab2_lds_bytes(int Cin, int W, int *npieces_out = nullptr) {
+    const int TQ = Cin == 32 ? 64 : 128, TP = Cin == 32 ? 256 : 128, NSTAGE = Cin == 32 ? 5 : 4;
+    const long long rows = TP + 2ll * W + 2;
+    const long long npieces = (rows * Cin * 2 + 1023) / 1024;
+    if (npieces_out) *npieces_out = (int)(npieces > 0x7fffffff ? 0x7fffffff : npieces);
+    long long lds = npieces * 1024 + NSTAGE * TQ * 64 + 1024;
+    if (lds < 4 * EpiGeom<4>::LDS_BYTES) lds = 4 * EpiGeom<4>::LDS_BYTES;
+    return lds > 0x7fffffff ? 0x7fffffff : (int)lds;
+}
+
 bool conv_slab2_eligible(const ConvArgs &a) {
     if (a.dtype != YMX_BF16 || a.k != 3 || a.stride != 1) return false;
-    if (a.Cin == 32) return a.Cout <= 64 && a.W <= 400;
-    if (a.Cin == 64) return a.Cout <= 128 && a.W <= 110;
-    return false;
+    if (!((a.Cin == 32 && a.Cout <= 64) || (a.Cin == 64 && a.Cout <= 128))) return false;
+    return slab2_lds_bytes(a.Cin, a.W) <= SLAB2_LDS_MAX;      // rows up to 343 / 111 pixels
 }
 
 template <typename OT, int CIN>
 static int launch_slab2_cfg(const ConvArgs &a, hipStream_t s) {
-    constexpr int TQ = CIN == 32 ? 64 : 128, TP = CIN == 32 ? 256 : 128;
-    const int rows = TP + 2 * a.W + 2;
-    const int npieces = (rows * CIN * 2 + 1023) / 1024;
-    constexpr int NSTAGE = CIN == 32 ? 5 : 4;
-    int lds = npieces * 1024 + NSTAGE * TQ * 64 + 1024;
-    if (lds < 4 * EpiGeom<4>::LDS_BYTES) lds = 4 * EpiGeom<4>::LDS_BYTES;
-    if (lds > 80 * 1024) return fail(YMX_EUNSUPPORTED, "conv_igemm_slab2: row of %d pixels too long", a.W);
+    constexpr int TP = CIN == 32 ? 256 : 128;
+    int npieces = 0;
+    const int lds = slab2_lds_bytes(CIN, a.W, &npieces);
+    if (lds > SLAB2_LDS_MAX) return fail(YMX_EUNSUPPORTED, "conv_igemm_slab2: row of %d pixels too long", a.W);
     auto kern = conv_igemm_slab2_kernel<OT, CIN>;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(YMX_ELAUNCH, "conv_igemm_slab2: cannot reserve 80 KB of LDS");
-        }
-        configured = true;
-    }
+    static LdsReserve reserved;        // one per kernel instantiation; remembers the devices already set up
+    if (const int rc = reserve_lds(reserved, (const void *)kern, 80 * 1024, "conv_igemm_slab2")) return rc;
     const long long grid = ((long long)a.P + TP - 1) / TP;
     if (grid > 0x7fffffffLL) return fail(YMX_EUNSUPPORTED, "conv_igemm_slab2: grid too large");
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a, npieces);

@@ -185,6 +185,9 @@ nms_class_kernel(const NmsArgs a) {
             }
             __syncthreads();
             const int cnt = s_cnt;
+            // every wave must have read the count before any wave appends the next chunk:
+            // the branch below contains barriers, so the decision has to be uniform
+            __syncthreads();
             if (cnt > NMS_BUF - NMS_CHUNK) {
                 for (int i = cnt + t; i < NMS_BUF; i += 256) buf[i] = 0;
                 __syncthreads();
@@ -350,15 +353,9 @@ int launch_nms(const NmsArgs &a, hipStream_t s) {
     while (npow2 < a.C * a.per_class) npow2 <<= 1;
     const size_t merge_lds = (size_t)npow2 * 16 + NMS_BINS * 4 + 32;
     if (merge_lds > 64 * 1024) {
-        static bool configured = false;
-        if (!configured) {
-            if (hipFuncSetAttribute((const void *)nms_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                (void)hipGetLastError();
-                return fail(YMX_ELAUNCH, "nms_merge: cannot reserve LDS");
-            }
-            configured = true;
-        }
         if (merge_lds > 160 * 1024) return fail(YMX_EUNSUPPORTED, "nms: C * per_class = %d too large", a.C * a.per_class);
+        static LdsReserve reserved;
+        if (const int rc = reserve_lds(reserved, (const void *)nms_merge_kernel, 160 * 1024, "nms_merge")) return rc;
     }
     hipLaunchKernelGGL(nms_merge_kernel, dim3(a.B), dim3(256), merge_lds, s, a, npow2);
     return check_launch("nms_merge");

@@ -55,11 +55,29 @@ class Detector(nn.Module):
         self.iou_threshold = iou_threshold
         self.score_threshold = score_threshold
         self._plans = {}
+        self._tensors = None                # parameters and buffers whose versions a plan depends on
 
     def load_reference_params(self, backbone_params, head_params):
         self.backbone.load_reference_params(backbone_params)
         self.head.load_reference_params(head_params)
         self._plans = {}
+        self._tensors = None
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float(): parameters move, every plan points at stale copies
+        out = super()._apply(fn, *args, **kwargs)
+        self._plans = {}
+        self._tensors = None
+        return out
+
+    def _versions(self):
+        """Version counters of every parameter and buffer.  A plan holds pointers to weights
+        packed from the parameters as they were when it was built; any in-place update since
+        (load_state_dict, an optimiser step, copy_) bumps a counter and the plan is rebuilt."""
+        ts = self._tensors
+        if ts is None:
+            ts = self._tensors = list(self.parameters()) + list(self.buffers())
+        return tuple(t._version for t in ts)
 
     @torch.no_grad()
     def calibrate_(self, x, out_std=2.0, seed=0):
@@ -116,7 +134,8 @@ class Detector(nn.Module):
         cdt = self.dtype
         code = _lib.dtype_code(cdt)
         ops = []
-        keep = []                       # tensors the program points at
+        keep = []                       # activation buffers the program points at
+        sites = []                      # (op index, layer, zero output channels appended) of every conv
 
         def buf(h, w, c, dtype=cdt):
             t = torch.empty((n, h, w, c), device=device, dtype=dtype)
@@ -124,7 +143,6 @@ class Detector(nn.Module):
             return t
 
         def conv(layer, x, h, w, residual=None, x_code=code, out_dtype=cdt, head=None):
-            wp, scale, shift, _src = layer.packed(cdt)
             oh, ow = layer.output_hw(h, w)
             cout = layer.filters
             if head is not None and cout % 8:
@@ -134,12 +152,7 @@ class Detector(nn.Module):
                 # exact zeros.  Rows are then 16-byte aligned and the convolution takes its
                 # vector store path; the caller sees the first `filters` channels as a view.
                 cout = (cout + 7) // 8 * 8
-                extra = cout - layer.filters
-                if scale is not None:
-                    scale = torch.cat([scale, scale.new_zeros(extra)])
-                if shift is not None:
-                    shift = torch.cat([shift, shift.new_zeros(extra)])
-            keep.extend([wp, scale, shift])
+            sites.append((len(ops), layer, cout - layer.filters))
             if head is None:
                 y = buf(oh, ow, cout, out_dtype)
             else:
@@ -155,9 +168,6 @@ class Detector(nn.Module):
             o.x_ld = o.res_ld = o.y_ld = 0
             o.min_tiles = min_tiles
             o.x = None if x is None else x.data_ptr()
-            o.w = wp.data_ptr()
-            o.scale = None if scale is None else scale.data_ptr()
-            o.shift = None if shift is None else shift.data_ptr()
             o.residual = None if residual is None else residual.data_ptr()
             o.y = y.data_ptr()
             if layer.act_fn is not None:
@@ -206,6 +216,8 @@ class Detector(nn.Module):
         part.ops = (_lib.ymx_op * len(ops))(*ops)
         part.n_ops = len(ops)
         part.keep = keep
+        part.sites = sites
+        self._bind_weights(part)
         part.x_offset = start * S * S * 3 * torch.empty((), dtype=x_dtype).element_size()
         C = self.num_classes
         padded = (s, m, l)                                  # this part's slices of the [B,S,S,cell_ld] maps
@@ -226,6 +238,24 @@ class Detector(nn.Module):
         part.nms_ws = torch.empty((max(part.nms_ws_bytes, 16),), device=device, dtype=torch.uint8)
         part.stream = part.done = None
         return part
+
+    def _bind_weights(self, part):
+        """Point every conv op of the part at the current packed weights / scale / shift of its
+        layer (YOLOConv.packed re-packs when a parameter has changed since it last did)."""
+        held = []
+        for idx, layer, extra in part.sites:
+            wp, scale, shift, _src = layer.packed(self.dtype)
+            if extra:
+                if scale is not None:
+                    scale = torch.cat([scale, scale.new_zeros(extra)])
+                if shift is not None:
+                    shift = torch.cat([shift, shift.new_zeros(extra)])
+            held.extend([wp, scale, shift])
+            o = part.ops[idx]
+            o.w = wp.data_ptr()
+            o.scale = None if scale is None else scale.data_ptr()
+            o.shift = None if shift is None else shift.data_ptr()
+        part.weights = held             # keeps the buffers alive for as long as the program names them
 
     def _build_plan(self, sizes, S, x_dtype, device):
         """One plan = the batch cut into len(sizes) consecutive sub-batches, each with its own
@@ -261,6 +291,7 @@ class Detector(nn.Module):
             start += n
         plan.start_event = torch.cuda.Event() if shared else None
         plan.heads = tuple(t[..., :3 * (5 + C)] for t in plan.padded)    # what callers see: [B,S,S,3*(5+C)]
+        plan.versions = self._versions()
         # single-part views kept for callers that inspect a plan (benchmarks, tests)
         first = plan.parts[0]
         plan.scales, plan.cap, plan.head_dtype = first.scales, first.cap, first.head_dtype
@@ -283,6 +314,12 @@ class Detector(nn.Module):
         key = (B, S, x_dtype, str(device))
         plan = self._plans.get(key)
         if plan is not None:
+            if plan.versions == self._versions():
+                return plan
+            # parameters were updated in place: same buffers and cut, freshly packed weights
+            for part in plan.parts:
+                self._bind_weights(part)
+            plan.versions = self._versions()
             return plan
         cands = self._candidate_splits(B, S)
         if len(cands) == 1:
@@ -336,7 +373,7 @@ class Detector(nn.Module):
 
     def _run_part(self, part, x_ptr, image_size, post):
         part.ops[0].x = x_ptr + part.x_offset
-        _lib.check(_lib.lib().ymx_run_program(part.ops, part.n_ops, _lib.stream()))
+        _lib.launch("ymx_run_program", part.boxes, part.ops, part.n_ops)
         if post:
             self._postprocess_part(part, image_size)
 
@@ -370,17 +407,17 @@ class Detector(nn.Module):
         sc = part.scales
         B, C = part.B, self.num_classes
         out_boxes, out_scores, out_classes, out_valid, out_keep = part.out
-        _lib.check(L.ymx_decode_filter_strided(sc.ptrs, sc.cell_ld, sc.n, sc.S, B, C, _lib.dtype_code(part.head_dtype),
+        _lib.launch("ymx_decode_filter_strided", part.boxes, sc.ptrs, sc.cell_ld, sc.n, sc.S, B, C, _lib.dtype_code(part.head_dtype),
                                                sc.anchors, sc.strides, sc.xyscale, 1, float(self.score_threshold),
                                                float(image_size), _lib.ptr(part.boxes), _lib.ptr(part.scores_cm),
                                                _lib.ptr(part.src_idx), _lib.ptr(part.counts), part.cap,
-                                               _lib.ptr(part.dec_ws), part.dec_ws_bytes, _lib.stream()))
-        _lib.check(L.ymx_nms_combined(_lib.ptr(part.boxes), _lib.ptr(part.scores_cm), _lib.ptr(part.counts),
+                                               _lib.ptr(part.dec_ws), part.dec_ws_bytes)
+        _lib.launch("ymx_nms_combined", part.boxes, _lib.ptr(part.boxes), _lib.ptr(part.scores_cm), _lib.ptr(part.counts),
                                       _lib.ptr(part.src_idx), B, part.cap, C, int(self.max_outputs_per_class),
                                       int(self.max_outputs), float(self.iou_threshold), float(self.score_threshold),
                                       _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_classes),
                                       _lib.ptr(out_valid), _lib.ptr(out_keep), _lib.ptr(part.nms_ws),
-                                      part.nms_ws_bytes, _lib.stream()))
+                                      part.nms_ws_bytes)
 
     def check_status(self):
         """Synchronises and raises if any decode+filter launch of this detector's plans left

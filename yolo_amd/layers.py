@@ -33,8 +33,8 @@ def affine_act(x, scale, shift, act):
     x = x.contiguous()
     y = torch.empty_like(x)
     c = x.shape[-1]
-    _lib.check(_lib.lib().ymx_affine_act(_lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y),
-                                         x.numel() // c, c, act, _lib.dtype_code(x.dtype), _lib.stream()))
+    _lib.launch("ymx_affine_act", x, _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y),
+                                         x.numel() // c, c, act, _lib.dtype_code(x.dtype))
     return y
 
 
@@ -112,8 +112,8 @@ def upsample2x_concat(skip, x):
             raise ValueError("upsample2x_concat: skip %s does not match 2x of %s" % (tuple(skip.shape), tuple(x.shape)))
         c1 = skip.shape[3]
     y = _empty_like_nhwc(x, c1 + c2, 2 * h, 2 * w)
-    _lib.check(_lib.lib().ymx_upsample2x_concat(_lib.ptr(skip), _lib.ptr(x), _lib.ptr(y), b, h, w, c1, c2,
-                                                _lib.dtype_code(x.dtype), _lib.stream()))
+    _lib.launch("ymx_upsample2x_concat", x, _lib.ptr(skip), _lib.ptr(x), _lib.ptr(y), b, h, w, c1, c2,
+                                                _lib.dtype_code(x.dtype))
     return y
 
 
@@ -211,7 +211,7 @@ class YOLOConv(nn.Module):
         nbytes = _lib.lib().ymx_packed_weight_bytes(k, cin, cout, code)
         wp = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         src = self.kernel.detach().float().contiguous()
-        _lib.check(_lib.lib().ymx_pack_weights(_lib.ptr(src), _lib.ptr(wp), k, cin, cout, code, _lib.stream()))
+        _lib.launch("ymx_pack_weights", wp, _lib.ptr(src), _lib.ptr(wp), k, cin, cout, code)
         if self.batch_normalization:
             scale, shift = self.bn.folded()
         else:
@@ -256,10 +256,9 @@ class YOLOConv(nn.Module):
                 raise ValueError("YOLOConv: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
             if residual.dtype != want:
                 residual = residual.to(want)
-        _lib.check(_lib.lib().ymx_conv2d_fused_ex(
-            _lib.ptr(x), _lib.ptr(wp), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual) if fuse_res else None,
+        _lib.launch("ymx_conv2d_fused_ex", x, _lib.ptr(x), _lib.ptr(wp), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual) if fuse_res else None,
             _lib.ptr(y), b, h, w, cin, cout, k, 2 if self.downsample else 1, self.act_code, code,
-            _lib.dtype_code(x.dtype), _lib.dtype_code(odt), 0, 0, 0, _lib.stream()))
+            _lib.dtype_code(x.dtype), _lib.dtype_code(odt), 0, 0, 0)
         if self.act_fn is not None:
             y = self.act_fn(y)
             if residual is not None:

@@ -93,9 +93,9 @@ def decode_heads(heads, num_classes, strides, xyscale, anchors, filter=False, sc
     L = _lib.lib()
     if split:
         conf = torch.empty((B, cap), device=dev, dtype=torch.float32)
-        _lib.check(L.ymx_decode_split(sc.ptrs, sc.n, sc.S, B, num_classes, _lib.dtype_code(dt), sc.anchors,
+        _lib.launch("ymx_decode_split", boxes, sc.ptrs, sc.n, sc.S, B, num_classes, _lib.dtype_code(dt), sc.anchors,
                                       sc.strides, sc.xyscale, _lib.ptr(boxes), _lib.ptr(conf), _lib.ptr(scores),
-                                      _lib.ptr(counts), cap, _lib.stream()))
+                                      _lib.ptr(counts), cap)
         out["conf"] = conf
         return out
     src_idx = ws = None
@@ -106,10 +106,10 @@ def decode_heads(heads, num_classes, strides, xyscale, anchors, filter=False, sc
         ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
         out["src_idx"] = src_idx
         out["workspace"] = ws
-    _lib.check(L.ymx_decode_filter(sc.ptrs, sc.n, sc.S, B, num_classes, _lib.dtype_code(dt), sc.anchors,
+    _lib.launch("ymx_decode_filter", boxes, sc.ptrs, sc.n, sc.S, B, num_classes, _lib.dtype_code(dt), sc.anchors,
                                    sc.strides, sc.xyscale, 1 if filter else 0, float(score_threshold),
                                    float(image_size), _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(src_idx),
-                                   _lib.ptr(counts), cap, _lib.ptr(ws), ws_bytes, _lib.stream()))
+                                   _lib.ptr(counts), cap, _lib.ptr(ws), ws_bytes)
     return out
 
 
@@ -187,9 +187,9 @@ def filter_bboxes(bboxes, scores, score_threshold, image_size):
     ws_bytes = L.ymx_filter_workspace_bytes(B, N)
     ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
     sb, sn, scs = sc.stride()
-    _lib.check(L.ymx_filter_boxes(_lib.ptr(bx), _lib.ptr(sc), sb, sn, scs, B, N, C, float(score_threshold),
+    _lib.launch("ymx_filter_boxes", boxes, _lib.ptr(bx), _lib.ptr(sc), sb, sn, scs, B, N, C, float(score_threshold),
                                   float(image_size), _lib.ptr(boxes), _lib.ptr(out_cm), _lib.ptr(src_idx),
-                                  _lib.ptr(counts), cap, _lib.ptr(ws), ws_bytes, _lib.stream()))
+                                  _lib.ptr(counts), cap, _lib.ptr(ws), ws_bytes)
     # one host read for both the largest survivor count and the kernel's status word
     host = torch.cat([counts.max().reshape(1), ws[:4].view(torch.int32)]).cpu()
     if int(host[1]) != 0:
@@ -229,10 +229,10 @@ def nms_class_major(boxes, scores_cm, counts, src_idx, max_output_size_per_class
     L = _lib.lib()
     ws_bytes = L.ymx_nms_workspace_bytes(B, C, int(max_output_size_per_class))
     ws = torch.empty((max(ws_bytes, 16),), device=dev, dtype=torch.uint8)
-    _lib.check(L.ymx_nms_combined(_lib.ptr(boxes), _lib.ptr(scores_cm), _lib.ptr(counts), _lib.ptr(src_idx), B, cap,
+    _lib.launch("ymx_nms_combined", boxes, _lib.ptr(boxes), _lib.ptr(scores_cm), _lib.ptr(counts), _lib.ptr(src_idx), B, cap,
                                   C, int(max_output_size_per_class), T, float(iou_threshold),
                                   float(score_threshold), _lib.ptr(ob), _lib.ptr(os_), _lib.ptr(oc), _lib.ptr(ov),
-                                  _lib.ptr(ok), _lib.ptr(ws), ws_bytes, _lib.stream()))
+                                  _lib.ptr(ok), _lib.ptr(ws), ws_bytes)
     return Detections(ob, os_, oc, ov, ok)
 
 
@@ -307,8 +307,7 @@ def _iou_call(bboxes1, bboxes2, giou):
     b1 = b1.contiguous()
     b2 = b2.contiguous()
     out = torch.empty(b1.shape[:-1], device=b1.device, dtype=torch.float32)
-    _lib.check(_lib.lib().ymx_bbox_iou(_lib.ptr(b1), _lib.ptr(b2), _lib.ptr(out), out.numel(), 1 if giou else 0,
-                                       _lib.stream()))
+    _lib.launch("ymx_bbox_iou", out, _lib.ptr(b1), _lib.ptr(b2), _lib.ptr(out), out.numel(), 1 if giou else 0)
     return out
 
 
