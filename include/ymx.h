@@ -220,6 +220,22 @@ int ymx_nms_combined(const float *boxes, const float *scores, const int *counts,
                      float *out_classes, int *out_valid, int *out_keep_idx, void *workspace,
                      size_t ws_bytes, void *stream);
 
+/* ymx_nms_combined for callers that cannot allocate or bring a workspace (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  Same arguments, semantics and results as
+ * ymx_nms_combined, minus the workspace: the per-class survivor lists live in a buffer of
+ * YMX_NMS_STATIC_SCRATCH_BYTES that is built into the library (one copy per GPU, held
+ * until the process ends).  The call allocates and frees nothing.  Sizes whose
+ * ymx_nms_workspace_bytes(B, C, per_class) exceeds the buffer are rejected with
+ * YMX_EUNSUPPORTED.  All calls on one GPU share that GPU's buffer: calls that may overlap
+ * in time on one GPU (different streams, different threads) race and must be serialised
+ * by the caller; calls on one stream are safe back to back. */
+#define YMX_NMS_STATIC_SCRATCH_BYTES (4 << 20)
+int ymx_nms_combined_static(const float *boxes, const float *scores, const int *counts,
+                            const int *src_idx, int B, int cap, int C, int per_class, int total,
+                            float iou_thr, float score_thr, float *out_boxes, float *out_scores,
+                            float *out_classes, int *out_valid, int *out_keep_idx, void *stream);
+
 /* ---- stand-alone per-channel affine + activation -----------------------------
  * Replaces Mish.call (layers.py:21-22: x*tanh(softplus(x))) and the inference form
  * of BatchNormalization.call (layers.py:11-15) when those layers are used on their

@@ -53,6 +53,7 @@ SIGNATURES = {
     "ymx_nms_workspace_bytes": (_sz, [_i, _i, _i]),
     "ymx_nms_combined": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp,
                               _vp, _sz, _vp]),
+    "ymx_nms_combined_static": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ymx_affine_act": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
     "ymx_bbox_iou": (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
 }

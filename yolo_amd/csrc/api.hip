@@ -32,7 +32,6 @@ int check_launch(const char *what) {
     return YMX_OK;
 }
 
-static bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 // Tuning options (ymx_set_option) are per calling thread: a thread that changes one affects
 // only its own later calls, so concurrent callers never see each other's settings and
@@ -405,35 +404,14 @@ int ymx_filter_boxes(const float *xywh, const float *scores, long long sb, long 
     return launch_decode(a, (hipStream_t)stream);
 }
 
-size_t ymx_nms_workspace_bytes(int B, int C, int per_class) {
-    if (B <= 0 || C <= 0 || per_class <= 0) return 0;
-    return (size_t)B * C * per_class * 8 + (((size_t)B * C * 4 + 15) & ~(size_t)15);
-}
+size_t ymx_nms_workspace_bytes(int B, int C, int per_class) { return nms_workspace_bytes(B, C, per_class); }
 
 int ymx_nms_combined(const float *boxes, const float *scores, const int *counts, const int *src_idx, int B, int cap,
                      int C, int per_class, int total, float iou_thr, float score_thr, float *out_boxes,
                      float *out_scores, float *out_classes, int *out_valid, int *out_keep_idx, void *workspace,
                      size_t ws_bytes, void *stream) {
-    if (!boxes || !scores || !out_boxes || !out_scores || !out_classes || !out_valid || !out_keep_idx)
-        return fail(YMX_EARG, "nms_combined: null pointer");
-    if (B <= 0 || cap <= 0 || C <= 0 || per_class <= 0 || total <= 0) return fail(YMX_EARG, "nms_combined: non-positive size");
-    if (cap & 3) return fail(YMX_EARG, "nms_combined: cap %d must be a multiple of 4", cap);
-    if (per_class > 64 || C > 2048 || (long long)C * per_class > 8192 || cap > (1 << 21))
-        return fail(YMX_EUNSUPPORTED, "nms_combined: limits per_class<=64, C<=2048, C*per_class<=8192, cap<=2097152");
-    if (!aligned16(boxes) || !aligned16(scores) || !aligned16(out_boxes)) return fail(YMX_EARG, "nms_combined: 16-byte alignment");
-    const size_t need = ymx_nms_workspace_bytes(B, C, per_class);
-    if (!workspace || ws_bytes < need) return fail(YMX_EWORKSPACE, "nms_combined: workspace %zu < %zu bytes", ws_bytes, need);
-    if (!aligned16(workspace)) return fail(YMX_EARG, "nms_combined: workspace must be 16-byte aligned");
-    NmsArgs a;
-    memset(&a, 0, sizeof(a));
-    a.boxes = boxes; a.scores = scores; a.counts = counts; a.src_idx = src_idx;
-    a.B = B; a.cap = cap; a.C = C; a.per_class = per_class; a.total = total;
-    a.iou_thr = iou_thr; a.score_thr = score_thr;
-    a.out_boxes = out_boxes; a.out_scores = out_scores; a.out_classes = out_classes;
-    a.out_valid = out_valid; a.out_keep = out_keep_idx;
-    a.kept_keys = (unsigned long long *)workspace;
-    a.kept_cnt = (int *)((char *)workspace + (size_t)B * C * per_class * 8);
-    return launch_nms(a, (hipStream_t)stream);
+    return nms_entry(boxes, scores, counts, src_idx, B, cap, C, per_class, total, iou_thr, score_thr, out_boxes,
+                     out_scores, out_classes, out_valid, out_keep_idx, workspace, ws_bytes, (hipStream_t)stream);
 }
 
 int ymx_affine_act(const void *x, const float *scale, const float *shift, void *y, long long n_pix, int C, int act,

@@ -11,6 +11,7 @@ namespace ymx {
 // ---- error reporting (thread-local message behind ymx_last_error) ------------
 int fail(int code, const char *fmt, ...);
 int check_launch(const char *what);
+static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 // ---- per-device kernel attributes ---------------------------------------------
 struct LdsReserve { std::atomic<unsigned long long> done{0}; };
@@ -251,5 +252,10 @@ struct NmsArgs {
     int *kept_cnt;                   // [B][C]
 };
 int launch_nms(const NmsArgs &a, hipStream_t s);
+size_t nms_workspace_bytes(int B, int C, int per_class);
+// argument checks + workspace carving + launch of ymx_nms_combined, shared by every NMS entry point
+int nms_entry(const float *boxes, const float *scores, const int *counts, const int *src_idx, int B, int cap, int C,
+              int per_class, int total, float iou_thr, float score_thr, float *out_boxes, float *out_scores,
+              float *out_classes, int *out_valid, int *out_keep_idx, void *workspace, size_t ws_bytes, hipStream_t s);
 
 }  // namespace ymx

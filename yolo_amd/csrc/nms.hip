@@ -28,6 +28,9 @@
 //
 // IoU arithmetic is fp32, in a fixed order, compiled without contraction, with a
 // correctly rounded division, so keep decisions are reproducible bit for bit.
+#include <atomic>
+#include <cstring>
+
 #include "common.h"
 
 namespace ymx {
@@ -361,4 +364,83 @@ int launch_nms(const NmsArgs &a, hipStream_t s) {
     return check_launch("nms_merge");
 }
 
+size_t nms_workspace_bytes(int B, int C, int per_class) {
+    if (B <= 0 || C <= 0 || per_class <= 0) return 0;
+    return (size_t)B * C * per_class * 8 + (((size_t)B * C * 4 + 15) & ~(size_t)15);
+}
+
+int nms_entry(const float *boxes, const float *scores, const int *counts, const int *src_idx, int B, int cap, int C,
+              int per_class, int total, float iou_thr, float score_thr, float *out_boxes, float *out_scores,
+              float *out_classes, int *out_valid, int *out_keep_idx, void *workspace, size_t ws_bytes, hipStream_t s) {
+    if (!boxes || !scores || !out_boxes || !out_scores || !out_classes || !out_valid || !out_keep_idx)
+        return fail(YMX_EARG, "nms_combined: null pointer");
+    if (B <= 0 || cap <= 0 || C <= 0 || per_class <= 0 || total <= 0) return fail(YMX_EARG, "nms_combined: non-positive size");
+    if (cap & 3) return fail(YMX_EARG, "nms_combined: cap %d must be a multiple of 4", cap);
+    if (per_class > 64 || C > 2048 || (long long)C * per_class > 8192 || cap > (1 << 21))
+        return fail(YMX_EUNSUPPORTED, "nms_combined: limits per_class<=64, C<=2048, C*per_class<=8192, cap<=2097152");
+    if (!aligned16(boxes) || !aligned16(scores) || !aligned16(out_boxes)) return fail(YMX_EARG, "nms_combined: 16-byte alignment");
+    const size_t need = nms_workspace_bytes(B, C, per_class);
+    if (!workspace || ws_bytes < need) return fail(YMX_EWORKSPACE, "nms_combined: workspace %zu < %zu bytes", ws_bytes, need);
+    if (!aligned16(workspace)) return fail(YMX_EARG, "nms_combined: workspace must be 16-byte aligned");
+    NmsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.boxes = boxes; a.scores = scores; a.counts = counts; a.src_idx = src_idx;
+    a.B = B; a.cap = cap; a.C = C; a.per_class = per_class; a.total = total;
+    a.iou_thr = iou_thr; a.score_thr = score_thr;
+    a.out_boxes = out_boxes; a.out_scores = out_scores; a.out_classes = out_classes;
+    a.out_valid = out_valid; a.out_keep = out_keep_idx;
+    a.kept_keys = (unsigned long long *)workspace;
+    a.kept_cnt = (int *)((char *)workspace + (size_t)B * C * per_class * 8);
+    return launch_nms(a, s);
+}
+
+// ---- the entry point that allocates nothing ---------------------------------------------
+// Per-class survivors (keys and counts, the same layout ymx_nms_combined carves out of the
+// caller's workspace) live in a device array that is part of the code object: every GPU the
+// library runs on holds its own copy, at its own address, until the process ends.
+static __device__ __align__(256) unsigned char scratch[YMX_NMS_STATIC_SCRATCH_BYTES];
+
+// `scratch` names a host-side handle, not device memory: the device address is looked up once
+// per device (with that device current) and only that address is ever handed to a kernel.
+static std::atomic<void *> g_scratch_ptr[64];
+
+static int scratch_address(void **out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(YMX_ELAUNCH, "nms_combined_static: no current device");
+    }
+    if (dev < 0 || dev >= 64) return fail(YMX_EUNSUPPORTED, "nms_combined_static: device index %d (at most 64 devices)", dev);
+    void *p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            (void)hipGetLastError();
+            return fail(YMX_ELAUNCH, "nms_combined_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+        }
+        g_scratch_ptr[dev].store(p, std::memory_order_release);      // every thread finds the same address
+    }
+    *out = p;
+    return YMX_OK;
+}
+
 }  // namespace ymx
+
+extern "C" int ymx_nms_combined_static(const float *boxes, const float *scores, const int *counts, const int *src_idx,
+                                       int B, int cap, int C, int per_class, int total, float iou_thr,
+                                       float score_thr, float *out_boxes, float *out_scores, float *out_classes,
+                                       int *out_valid, int *out_keep_idx, void *stream) {
+    using namespace ymx;
+    if (B <= 0 || C <= 0 || per_class <= 0) return fail(YMX_EARG, "nms_combined_static: non-positive size");
+    const size_t need = nms_workspace_bytes(B, C, per_class);
+    if (need > (size_t)YMX_NMS_STATIC_SCRATCH_BYTES)
+        return fail(YMX_EUNSUPPORTED, "nms_combined_static: B*C*per_class = %lld needs %zu bytes of scratch, the built-in "
+                    "buffer holds %d (use ymx_nms_combined with a workspace)", (long long)B * C * per_class, need,
+                    YMX_NMS_STATIC_SCRATCH_BYTES);
+    void *ws = nullptr;
+    if (const int rc = scratch_address(&ws)) return rc;
+    // Nothing in the buffer has to start at zero: kernel 1 writes the count of every (image,
+    // class) and kernel 2 reads only the keys below that count.
+    return nms_entry(boxes, scores, counts, src_idx, B, cap, C, per_class, total, iou_thr, score_thr, out_boxes,
+                     out_scores, out_classes, out_valid, out_keep_idx, ws, need, (hipStream_t)stream);
+}
