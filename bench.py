@@ -70,18 +70,169 @@ PMC_KERNEL = {
 }
 
 
-def pmc_traffic(label):
-    """HBM bytes per launch of the labelled kernel, from the newest committed --pmc summary."""
+def pmc_traffic(label, pattern="r*_pmc_traffic.json", kernel=None):
+    """HBM bytes per launch of a kernel, from the newest committed --pmc summary matching
+    ``pattern`` under profiles/ (None when there is none)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files or label not in PMC_KERNEL:
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    kernel = kernel or PMC_KERNEL.get(label)
+    if not files or kernel is None:
         return None
     try:
         with open(files[-1]) as f:
-            k = json.load(f)["kernels"].get(PMC_KERNEL[label])
+            k = json.load(f)["kernels"].get(kernel)
         return None if k is None else round(k["hbm_bytes_per_launch"], 1)
     except (OSError, ValueError, KeyError):
         return None
+
+
+def _sum_traffic(pattern, prefixes):
+    """Summed HBM bytes per step of every kernel whose name starts with one of ``prefixes``."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            ks = json.load(f)["kernels"]
+        tot = [v["hbm_bytes_per_launch"] * v.get("launches_per_step", 1.0) for k, v in ks.items() if k.startswith(prefixes)]
+        return round(sum(tot), 1) if tot else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def time_postproc_split(run_decode, run_nms, steps):
+    """decode+filter and NMS timed apart with events between the two calls on the stream they
+    run on (ms per call each)."""
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    run_decode(); run_nms()
+    torch.cuda.synchronize()
+    for e in ev:
+        e[0].record(); run_decode(); e[1].record(); run_nms(); e[2].record()
+    torch.cuda.synchronize()
+    dec = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
+    nms = sum(e[1].elapsed_time(e[2]) for e in ev) / steps
+    return dec, nms
+
+
+def hbm_roofline(kernel, bytes_per_launch, ms, traffic):
+    gbs = bytes_per_launch / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
+            "avg_launch_ms": round(ms, 4)}
+
+
+def postproc_bytes(B, N, C, m_mean, head_bytes, total=32):
+    """Algorithmic bytes of one decode+filter call and of one combined-NMS call over B images:
+    decode reads every logit once and writes box + class-major score column + source index
+    per survivor (+ the count); NMS reads each survivor's box and scores once and writes the
+    detection records."""
+    dec = B * (N * (5 + C) * head_bytes + m_mean * (4 + C + 1) * 4 + 4)
+    nms = B * (m_mean * (4 + C) * 4 + total * 6 * 4 + 4 + total * 4)
+    return dec, nms
+
+
+def stress_workload(args, dev):
+    """BASELINE config 4: decode + filter + combined NMS alone on synthetic head maps of a
+    1280x1280 input (100 800 candidates per image, 80 classes, score threshold 0.001)."""
+    from yolo_amd import _lib
+    from yolo_amd import utils as U
+    import yolo_amd as Y
+    B, C = args.batch, args.classes
+    sides = (160, 80, 40)
+    heads = []
+    for seed, S in zip((10, 11, 12), sides):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        h = torch.empty(B, S, S, 3, 5 + C)
+        for i in range(B):                           # image by image: bounded host memory
+            h[i] = torch.randn(S, S, 3, 5 + C, generator=g) * 2.0
+        h[..., 4] += 6.0                             # objectness bias: nearly every candidate passes 0.001
+        heads.append(h.to(dev))
+    cfg = Y.config
+    sc = U._Scales(heads, cfg["strides"], cfg["xyscale"], U.default_anchors())
+    N = sc.N
+    cap = U._round4(N)
+    f32, i32 = torch.float32, torch.int32
+    boxes = torch.empty((B, cap, 4), device=dev, dtype=f32)
+    scores = torch.empty((B, C, cap), device=dev, dtype=f32)
+    src = torch.empty((B, cap), device=dev, dtype=i32)
+    counts = torch.empty((B,), device=dev, dtype=i32)
+    T = 32
+    outs = [torch.empty((B, T, 4), device=dev, dtype=f32), torch.empty((B, T), device=dev, dtype=f32),
+            torch.empty((B, T), device=dev, dtype=f32), torch.empty((B,), device=dev, dtype=i32),
+            torch.empty((B, T), device=dev, dtype=i32)]
+    L = _lib.lib()
+    dws_n = L.ymx_decode_workspace_bytes(B, sc.n, sc.S)
+    dws = torch.empty((dws_n,), device=dev, dtype=torch.uint8)
+    nws_n = L.ymx_nms_workspace_bytes(B, C, 32)
+    nws = torch.empty((nws_n,), device=dev, dtype=torch.uint8)
+    thr, size = 0.001, 1280.0
+
+    def run_decode():
+        _lib.launch("ymx_decode_filter", boxes, sc.ptrs, sc.n, sc.S, B, C, _lib.F32, sc.anchors, sc.strides, sc.xyscale,
+                    1, thr, size, _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(src), _lib.ptr(counts), cap,
+                    _lib.ptr(dws), dws_n)
+
+    def run_nms():
+        _lib.launch("ymx_nms_combined", boxes, _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(counts), _lib.ptr(src), B, cap,
+                    C, 32, T, 0.45, thr, *[_lib.ptr(t) for t in outs], _lib.ptr(nws), nws_n)
+
+    def step():
+        run_decode(); run_nms()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms_per_step = elapsed / args.steps * 1e3
+    m_mean = float(counts.float().mean().item())
+    dec_ms, nms_ms = time_postproc_split(run_decode, run_nms, max(3, min(args.steps, 20)))
+    dec_b, nms_b = postproc_bytes(B, N, C, m_mean, 4)
+    pat = "r*_pmc_traffic_stress.json"
+    line = {
+        "metric": "images/sec (decode+filter+NMS only) NMS stress", "value": round(B * args.steps / elapsed, 2),
+        "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "candidates_per_s": round(B * N * args.steps / elapsed, 1),
+        "config": {"workload": "NMS stress: decode + filter + combined NMS on synthetic fp32 head maps "
+                               "[%d,160,160,3,%d] [..,80,80,..] [..,40,40,..] (N(0,2^2) logits, objectness +6, seeds 10/11/12), "
+                               "%d candidates per image, %d classes, score threshold 0.001, IoU 0.45, 32 per class, 32 total"
+                               % (B, 5 + C, N, C),
+                   "batch": B, "candidates_per_image": N, "num_classes": C, "mean_survivors_per_image": m_mean,
+                   "mean_valid_detections": float(outs[3].float().mean().item())},
+        "roofline": hbm_roofline("decode_kernel<float, 20, 1>", dec_b, dec_ms, pmc_traffic(None, pat, "decode_kernel<float, 20, 1>")),
+        "roofline_nms": hbm_roofline("nms_class_kernel + nms_merge_kernel", nms_b, nms_ms, _sum_traffic(pat, ("nms_",))),
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_stress(C)
+    print(json.dumps(line), flush=True)
+
+
+def cpu_baseline_stress(C, budget_s=15.0):
+    """The C oracle's decode + filter + NMS on one stress image at a time, on this host."""
+    import numpy as np
+    from oracle import cref
+    rng = np.random.default_rng(10)
+    heads = []
+    for S in (160, 80, 40):
+        h = (rng.standard_normal((1, S, S, 3, 5 + C)) * 2.0).astype(np.float32)
+        h[..., 4] += 6.0
+        heads.append(h)
+    cref.bbox_nms(heads, 1280.0, C, 32, 32, 0.45, 0.001)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        cref.bbox_nms(heads, 1280.0, C, 32, 32, 0.45, 0.001)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 64:
+            break
+    return {"value": round(n / dt, 3), "unit": "images/s", "cores": 1, "kind": "port",
+            "sample": "%d stress images (100 800 candidates, 80 classes) through the C oracle's decode/filter/NMS, one thread (%.1f s)" % (n, dt)}
 
 
 def conv_flops(op):
@@ -178,6 +329,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--per-op", action="store_true", help="also print the per-launch table to stderr")
+    ap.add_argument("--workload", default="detector", choices=["detector", "nms-stress"],
+                    help="detector (default): the whole hot path; nms-stress: decode+filter+NMS alone on 100 800 "
+                         "synthetic candidates per image (use --batch 32)")
     ap.add_argument("--split", default="auto", help="sub-batches run concurrently on separate streams: "
                     "auto (timed once), off, or sizes such as 48,16")
     args = ap.parse_args()
@@ -201,6 +355,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+
+    if args.workload == "nms-stress":
+        if world != 1:
+            raise SystemExit("the nms-stress workload is a single-GPU measurement")
+        if args.batch == 64:
+            args.batch = 32                          # the configuration's batch unless overridden
+        stress_workload(args, dev)
+        return
 
     from yolo_amd import Detector
     from yolo_amd import dist as ydist
@@ -274,11 +436,18 @@ def main():
                             "measured": "whole batch as one program, each launch alone on the GPU"}
         plan = whole
         post_ms = time_postproc(det, plan, x, max(3, min(args.steps, 10)))
+        part = plan.parts[0]
+        dec_ms, nms_ms = time_postproc_split(lambda: det._decode_part(part, S), lambda: det._nms_part(part),
+                                             max(3, min(args.steps, 10)))
         N = plan.scales.N
         m_mean = float(plan.counts.float().mean().item())
-        head_e = 4
-        dec_bytes = B * (N * (5 + C) * head_e + m_mean * (4 + C + 1) * 4 + 4)
-        nms_bytes = B * (m_mean * (4 + C) * 4 + 32 * 6 * 4 + 4 + 32 * 4)
+        dec_bytes, nms_bytes = postproc_bytes(B, N, C, m_mean, 4)
+        # the bandwidth-bound half of the path, on the same line the driver keeps
+        line["roofline"]["hbm"] = {
+            "decode": hbm_roofline("decode_kernel<float, 20, 1>", dec_bytes, dec_ms,
+                                   pmc_traffic(None, kernel="decode_kernel<float, 20, 1>")),
+            "nms": hbm_roofline("nms_class_kernel + nms_merge_kernel", nms_bytes, nms_ms,
+                                _sum_traffic("r*_pmc_traffic.json", ("nms_",)))}
         line["breakdown"] = {
             "conv_stack_ms": round(conv_ms, 4), "conv_stack_tflops": round(conv_flops_total / (conv_ms * 1e-3) / 1e12, 2),
             "conv_stack_frac_of_bf16_peak": round(conv_flops_total / (conv_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),

@@ -1,0 +1,56 @@
+"""In-kernel timeline of the decode+filter kernel on the NMS-stress heads (tuning aid).
+
+    make -C yolo_amd/csrc stamps && python tools/stamp_decode.py [batch]
+
+Prints, per interval of a workgroup's life, the median / p10 / p90 over the stamped
+workgroups in microseconds (100 MHz wall clock).
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from yolo_amd import _lib                      # noqa: E402
+
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libymx_stamps.so")
+import yolo_amd as Y                            # noqa: E402
+from yolo_amd import utils as U                 # noqa: E402
+
+NBLK = 16384
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    C = 80
+    g = torch.Generator().manual_seed(10)
+    heads = []
+    for S in (160, 80, 40):
+        h = torch.randn(B, S, S, 3, 5 + C, generator=g) * 2
+        h[..., 4] += 6.0
+        heads.append(h.cuda())
+    cfg = Y.config
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    reader = handle.ymx_debug_stamps_decode
+    reader.restype = ctypes.c_int
+    reader.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    for _ in range(3):
+        r = U.decode_heads(heads, C, cfg["strides"], cfg["xyscale"], U.default_anchors(), filter=True,
+                           score_threshold=0.001, image_size=1280.0)
+    torch.cuda.synchronize()
+    buf = np.zeros((NBLK, 8), dtype=np.uint64)
+    assert reader(buf.ctypes.data, buf.nbytes) == 0
+    s = buf[buf[:, 0] != 0].astype(np.int64)
+    names = ["wait for rows", "compute + ballot", "publish, next rows, look-back", "stores", "iteration"]
+    print("%d workgroups stamped at their 11th segment" % s.shape[0])
+    for i in range(5):
+        d = (s[:, i + 1] - s[:, i]) if i < 4 else (s[:, 4] - s[:, 0])
+        d = d / 100.0
+        print("  %-18s median %7.2f  p10 %7.2f  p90 %7.2f us" % (names[i], np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+    print("  span of the stamped iterations %.1f us" % ((s[:, 4].max() - s[:, 0].min()) / 100.0))
+
+
+if __name__ == "__main__":
+    main()

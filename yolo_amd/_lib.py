@@ -8,7 +8,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libymx.so")
+# YMX_LIBRARY names another build of the same library (diagnostic builds); the default is the
+# one next to this file
+LIB_PATH = os.environ.get("YMX_LIBRARY") or os.path.join(_HERE, "libymx.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_MISH = 0, 1, 2

@@ -290,7 +290,7 @@ static size_t decode_ws_bytes(int B, int nseg) {
 }
 static int count_segments(int n_scales, const int *S) {
     int n = 0;
-    for (int i = 0; i < n_scales; ++i) n += (3 * S[i] * S[i] + 255) / 256;
+    for (int i = 0; i < n_scales; ++i) n += (3 * S[i] * S[i] + DEC_SEG - 1) / DEC_SEG;
     return n;
 }
 
@@ -331,7 +331,7 @@ int ymx_decode_filter(const void *const *head, int n_scales, const int *S, int B
         if (!head[i] || S[i] <= 0) return fail(YMX_EARG, "decode_filter: scale %d missing", i);
         a.head[i] = head[i]; a.S[i] = S[i];
         a.seg_begin[i] = nseg; a.cand_begin[i] = ncand;
-        nseg += (3 * S[i] * S[i] + 255) / 256; ncand += 3 * S[i] * S[i];
+        nseg += (3 * S[i] * S[i] + DEC_SEG - 1) / DEC_SEG; ncand += 3 * S[i] * S[i];
         a.stride[i] = strides[i]; a.xyscale[i] = xyscale[i];
         for (int j = 0; j < 6; ++j) (&a.anchor[i][0][0])[j] = anchors[i * 6 + j];
     }
@@ -348,6 +348,11 @@ int ymx_decode_filter(const void *const *head, int n_scales, const int *S, int B
             a.cell_ld[i] = g_cell_ld[i];
             if (pad > a.max_pad) a.max_pad = pad;
         }
+    }
+    for (int i = 0; i < n_scales; ++i) {
+        const int ld = a.cell_ld[i] ? a.cell_ld[i] : 3 * (5 + C);
+        const unsigned long long bytes = ((unsigned long long)B * S[i] * S[i] - 1) * ld * 4 + 3ull * (5 + C) * 4;
+        a.head_bytes[i] = (head_dtype == YMX_F32 && bytes < 0xffffff00ull) ? (unsigned)bytes : 0u;
     }
     if (!filter && cap < ncand) return fail(YMX_EARG, "decode_filter: cap %d < %d candidates", cap, ncand);
     if (filter) {
@@ -382,7 +387,7 @@ int ymx_decode_split(const void *const *head, int n_scales, const int *S, int B,
 
 size_t ymx_filter_workspace_bytes(int B, int N) {
     if (B <= 0 || N <= 0) return 0;
-    return decode_ws_bytes(B, (N + 255) / 256);
+    return decode_ws_bytes(B, (N + DEC_SEG - 1) / DEC_SEG);
 }
 
 int ymx_filter_boxes(const float *xywh, const float *scores, long long sb, long long sn, long long sc, int B, int N,
@@ -395,7 +400,7 @@ int ymx_filter_boxes(const float *xywh, const float *scores, long long sb, long 
     DecodeArgs a;
     memset(&a, 0, sizeof(a));
     a.n_scales = 1; a.S[0] = 1; a.seg_begin[0] = 0; a.cand_begin[0] = 0;
-    a.nseg = (N + 255) / 256; a.seg_begin[1] = a.nseg; a.cand_begin[1] = N;
+    a.nseg = (N + DEC_SEG - 1) / DEC_SEG; a.seg_begin[1] = a.nseg; a.cand_begin[1] = N;
     a.B = B; a.C = C; a.N = N; a.cap = cap; a.filter = 2; a.thr = thr; a.image_size = image_size;
     a.in_xywh = xywh; a.in_scores = scores; a.sb = sb; a.sn = sn; a.sc = sc;
     a.boxes = boxes; a.scores = out_scores; a.src_idx = src_idx; a.counts = counts;

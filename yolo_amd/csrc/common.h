@@ -113,7 +113,10 @@ template <int ACT> __device__ __forceinline__ f32x2_t affine_act2(f32x2_t v, f32
     f32x2_t o = {act_c<ACT>(x.x), act_c<ACT>(x.y)};
     return o;
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// 1 / (1 + e^-x) with the hardware exponential and reciprocal (1 ulp each): four instructions
+// instead of the dozen a correctly rounded division takes; the decode kernel spends most of
+// its arithmetic here.
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // ---- launchers (one per kernel family; defined next to the kernels) -----------
 struct ConvArgs {
@@ -218,10 +221,18 @@ int launch_affine_act(const void *x, const float *scale, const float *shift, voi
 int launch_bbox_iou(const float *b1, const float *b2, float *out, long long n, int giou,
                     hipStream_t s);
 
+// A decode workgroup (256 threads) owns a segment of DEC_SEG consecutive candidates of one
+// scale of one image, walked in DEC_SS sub-steps of 64.
+#ifndef YMX_DEC_SS
+#define YMX_DEC_SS 1
+#endif
+constexpr int DEC_SS = YMX_DEC_SS, DEC_SEG = 64 * DEC_SS;
+
 struct DecodeArgs {
     const void *head[3];
+    unsigned head_bytes[3];      // byte extent of each fp32 map if it can be addressed as one buffer (< 4 GiB), else 0
     int S[3];
-    int seg_begin[4];            // first segment of each scale (segments of 256 candidates)
+    int seg_begin[4];            // first segment of each scale (segments of DEC_SEG candidates)
     int cand_begin[4];           // first candidate of each scale in the concatenated list
     float stride[3], xyscale[3], anchor[3][3][2];
     int cell_ld[3];              // elements from one grid cell to the next (>= 3*(5+C)); 0 = dense

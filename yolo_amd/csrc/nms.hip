@@ -105,6 +105,12 @@ __device__ __forceinline__ void hist_cut(const int *hist, int target, int t, int
     __syncthreads();
 }
 
+// One 1024-candidate chunk of a score row as this thread sees it: four consecutive scores.
+__device__ __forceinline__ float4 load_chunk(const float *__restrict__ col, int i0, int M) {
+    // rows are padded to a multiple of 4 (cap % 4 == 0), so a vector that starts below M is in bounds
+    return i0 < M ? *(const float4 *)(col + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 __global__ void __launch_bounds__(256)
 nms_class_kernel(const NmsArgs a) {
     __shared__ u64 buf[NMS_BUF];
@@ -133,6 +139,21 @@ nms_class_kernel(const NmsArgs a) {
     int target = 8 * PC;
     target = target < 64 ? 64 : (target > NMS_KEEP ? NMS_KEEP : target);
 
+    // The floor comes from a SAMPLE of the row: every k-th chunk (k grows with the row, up to
+    // 8), and the bin edge above which the sample holds its share of `target` candidates plus
+    // three standard deviations.  A sampled floor can only be too low (more keys than needed:
+    // the buffer is cut) or too high (fewer than per_class boxes survive: a further tier
+    // rescans below it); the result never depends on it, and a long row is read 1 + 1/k times
+    // instead of twice.
+    const int nchunk = (M + NMS_CHUNK - 1) / NMS_CHUNK;
+    int kstep = nchunk / 4;
+    kstep = kstep < 1 ? 1 : (kstep > 8 ? 8 : kstep);
+    int starget = target;
+    if (kstep > 1) {
+        const float share = (float)target / (float)kstep;
+        starget = (int)(share + 3.0f * sqrtf(share)) + 4;
+    }
+
     // wave 0: kept box j lives in lane j
     float ky1 = 0.f, kx1 = 0.f, ky2 = 0.f, kx2 = 0.f, kar = 0.f;
     u64 kkey = 0;
@@ -140,66 +161,114 @@ nms_class_kernel(const NmsArgs a) {
     u64 ceil_key = ~0ull;           // keys must be < ceil_key
 
     for (;;) {   // one pass per tier
-        // ---- starting floor: the highest bin edge with at least `target` candidates above it
+        // ---- starting floor: the highest bin edge with at least `starget` sampled candidates above it
         for (int i = t; i < NMS_BINS; i += 256) hist[i] = 0;
         if (t == 0) { s_cnt = 0; s_cutbin = 0; }
         __syncthreads();
-        for (int base = 0; base < M; base += NMS_CHUNK) {
-            const int i0 = base + t * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i0 < M) v = *(const float4 *)(col + i0);
-            const float sv[4] = {v.x, v.y, v.z, v.w};
+        for (int j0 = 0; j0 < nchunk; j0 += 4 * kstep) {
+            float4 v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int idx = i0 + e;
-                const float s = sv[e];
-                const u32 ob = ord_bits(s);
-                const u64 key = ((u64)ob << 32) | (u64)(0xffffffffu - (u32)idx);
-                if (idx < M && s > a.score_thr && key < ceil_key) {
-                    const u32 bin = (ob - ob_thr) >> hshift;
-                    atomicAdd(&hist[bin < (u32)NMS_BINS ? bin : NMS_BINS - 1], 1);
+            for (int u = 0; u < 4; ++u) v[u] = load_chunk(col, (j0 + u * kstep) * NMS_CHUNK + t * 4, (j0 + u * kstep) < nchunk ? M : 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i0 = (j0 + u * kstep) * NMS_CHUNK + t * 4;
+                const float sv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int idx = i0 + e;
+                    const float s = sv[e];
+                    const u32 ob = ord_bits(s);
+                    const u64 key = ((u64)ob << 32) | (u64)(0xffffffffu - (u32)idx);
+                    if ((j0 + u * kstep) < nchunk && idx < M && s > a.score_thr && key < ceil_key) {
+                        const u32 bin = (ob - ob_thr) >> hshift;
+                        atomicAdd(&hist[bin < (u32)NMS_BINS ? bin : NMS_BINS - 1], 1);
+                    }
                 }
             }
         }
         __syncthreads();
-        hist_cut(hist, target, t, s_wsum, &s_cutbin);
-        const int cutbin = s_cutbin;   // 0: fewer than `target` candidates in all, take everything
+        hist_cut(hist, starget, t, s_wsum, &s_cutbin);
+        const int cutbin = s_cutbin;   // 0: fewer than `starget` sampled candidates in all, take everything
         u64 floor_key = cutbin > 0 ? (((u64)(ob_thr + ((u32)cutbin << hshift))) << 32) - 1ull : 0ull;   // keys must be > floor_key
         bool cut = cutbin > 0;
-        for (int base = 0; base < M; base += NMS_CHUNK) {
-            const int i0 = base + t * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i0 < M) v = *(const float4 *)(col + i0);
-            const float sv[4] = {v.x, v.y, v.z, v.w};
+
+        // ---- key pass, fast form: no barrier inside the loop.  Keys above the floor are
+        // appended (ballot + one LDS atomic per wave); positions beyond the buffer are counted
+        // but not stored, and if that happened the pass is repeated in the careful form below.
+        {
+            float4 nxt[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int idx = i0 + e;
-                const float s = sv[e];
-                const u64 key = ((u64)ord_bits(s) << 32) | (u64)(0xffffffffu - (u32)idx);
-                const bool pred = idx < M && s > a.score_thr && key > floor_key && key < ceil_key;
-                const u64 bal = __ballot(pred);
-                if (bal) {
-                    const int leader = __ffsll((long long)bal) - 1;
-                    int pos = 0;
-                    if (lane == leader) pos = atomicAdd(&s_cnt, __popcll(bal));
-                    pos = __shfl(pos, leader);
-                    if (pred) buf[pos + __popcll(bal & below)] = key;
+            for (int u = 0; u < 4; ++u) nxt[u] = load_chunk(col, u * NMS_CHUNK + t * 4, M);
+            for (int j0 = 0; j0 < nchunk; j0 += 4) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = nxt[u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) nxt[u] = load_chunk(col, (j0 + 4 + u) * NMS_CHUNK + t * 4, M);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i0 = (j0 + u) * NMS_CHUNK + t * 4;
+                    const float sv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int idx = i0 + e;
+                        const float s = sv[e];
+                        const u64 key = ((u64)ord_bits(s) << 32) | (u64)(0xffffffffu - (u32)idx);
+                        const bool pred = idx < M && s > a.score_thr && key > floor_key && key < ceil_key;
+                        const u64 bal = __ballot(pred);
+                        if (bal) {
+                            const int leader = __ffsll((long long)bal) - 1;
+                            int pos = 0;
+                            if (lane == leader) pos = atomicAdd(&s_cnt, __popcll(bal));
+                            pos = __shfl(pos, leader);
+                            pos += __popcll(bal & below);
+                            if (pred && pos < NMS_BUF) buf[pos] = key;
+                        }
+                    }
                 }
             }
+        }
+        __syncthreads();
+        if (s_cnt > NMS_BUF) {
+            // ---- careful form: capacity checked after every chunk; when the buffer could
+            // overflow it is sorted, cut to its best NMS_KEEP keys and the floor is raised
             __syncthreads();
-            const int cnt = s_cnt;
-            // every wave must have read the count before any wave appends the next chunk:
-            // the branch below contains barriers, so the decision has to be uniform
+            if (t == 0) s_cnt = 0;
             __syncthreads();
-            if (cnt > NMS_BUF - NMS_CHUNK) {
-                for (int i = cnt + t; i < NMS_BUF; i += 256) buf[i] = 0;
+            for (int base = 0; base < M; base += NMS_CHUNK) {
+                const int i0 = base + t * 4;
+                const float4 v = load_chunk(col, i0, M);
+                const float sv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int idx = i0 + e;
+                    const float s = sv[e];
+                    const u64 key = ((u64)ord_bits(s) << 32) | (u64)(0xffffffffu - (u32)idx);
+                    const bool pred = idx < M && s > a.score_thr && key > floor_key && key < ceil_key;
+                    const u64 bal = __ballot(pred);
+                    if (bal) {
+                        const int leader = __ffsll((long long)bal) - 1;
+                        int pos = 0;
+                        if (lane == leader) pos = atomicAdd(&s_cnt, __popcll(bal));
+                        pos = __shfl(pos, leader);
+                        if (pred) buf[pos + __popcll(bal & below)] = key;
+                    }
+                }
                 __syncthreads();
-                bitonic_desc(buf, NMS_BUF, t);
-                floor_key = buf[NMS_KEEP - 1];
-                cut = true;
+                const int cnt = s_cnt;
+                // every wave must have read the count before any wave appends the next chunk:
+                // the branch below contains barriers, so the decision has to be uniform
                 __syncthreads();
-                if (t == 0) s_cnt = NMS_KEEP;
-                __syncthreads();
+                if (cnt > NMS_BUF - NMS_CHUNK) {
+                    for (int i = cnt + t; i < NMS_BUF; i += 256) buf[i] = 0;
+                    __syncthreads();
+                    bitonic_desc(buf, NMS_BUF, t);
+                    floor_key = buf[NMS_KEEP - 1];
+                    cut = true;
+                    __syncthreads();
+                    if (t == 0) s_cnt = NMS_KEEP;
+                    __syncthreads();
+                }
             }
         }
         const int n = s_cnt;
@@ -255,7 +324,8 @@ nms_class_kernel(const NmsArgs a) {
         __syncthreads();
     }
     if (t < 64) {
-        if (lane < nkept) a.kept_keys[((size_t)b * a.C + c) * PC + lane] = kkey;
+        // every slot of the class is written (zero = empty), so the merge reads them unconditionally
+        if (lane < PC) a.kept_keys[((size_t)b * a.C + c) * PC + lane] = lane < nkept ? kkey : 0ull;
         if (lane == 0) a.kept_cnt[b * a.C + c] = nkept;
     }
 }
@@ -271,35 +341,58 @@ nms_merge_kernel(const NmsArgs a, const int npow2) {
     u64 *keys = (u64 *)smem_raw;                 // [npow2] all keys, then the sorted selection
     u64 *sel = keys + npow2;                     // [npow2] selection
     int *hist = (int *)(sel + npow2);            // [NMS_BINS]
-    int *s_misc = hist + NMS_BINS;               // [0..3] wave sums, [4] cut bin, [5] selected, [6] n valid
+    int *s_misc = hist + NMS_BINS;               // [0..3] wave sums, [4] cut bin, [5] selected, [8..11] / [12..15] wave minima / maxima
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63;
     const int PC = a.per_class, nslots = a.C * PC;
     const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const u32 ob_thr = ord_bits(a.score_thr);
-    int hshift = 0;
-    {
-        const u32 range = (a.score_thr < 1.0f) ? ord_bits(1.0f) - ob_thr : (1u << 23);
-        while ((range >> hshift) >= (u32)NMS_BINS) ++hshift;
-    }
-    auto bin_of = [&](u64 key) {
-        const u32 bin = ((u32)(key >> 32) - ob_thr) >> hshift;
-        return bin < (u32)NMS_BINS ? (int)bin : NMS_BINS - 1;
-    };
     for (int i = t; i < NMS_BINS; i += 256) hist[i] = 0;
-    if (t < 8) s_misc[t] = 0;
-    __syncthreads();
+    if (t < 8) s_misc[t] = 0;                    // [8..15] are written by every wave before they are read
+    // all slots of the image are contiguous and empty ones are zero: plain coalesced loads,
+    // independent of each other (several in flight per thread)
+    const u64 *__restrict__ kk = a.kept_keys + (size_t)b * nslots;
+    u32 lmin = 0xffffffffu, lmax = 0u;
+#pragma unroll 4
     for (int i = t; i < npow2; i += 256) {
         u64 key = 0;
-        if (i < nslots) {
-            const int c = i / PC, j = i - c * PC;
-            if (j < a.kept_cnt[b * a.C + c]) {
-                const u64 k1 = a.kept_keys[((size_t)b * a.C + c) * PC + j];
-                const u32 idx = 0xffffffffu - (u32)k1;
-                key = (k1 & 0xffffffff00000000ull) | ((u64)(0x7ffu - (u32)c) << 21) | (u64)(0x1fffffu - idx);
-                atomicAdd(&hist[bin_of(key)], 1);
-            }
+        const u64 k1 = i < nslots ? kk[i] : 0ull;
+        if (k1 != 0) {
+            const int c = i / PC;
+            const u32 idx = 0xffffffffu - (u32)k1;
+            key = (k1 & 0xffffffff00000000ull) | ((u64)(0x7ffu - (u32)c) << 21) | (u64)(0x1fffffu - idx);
+            const u32 o = (u32)(k1 >> 32);
+            lmin = o < lmin ? o : lmin;
+            lmax = o > lmax ? o : lmax;
         }
         keys[i] = key;
+    }
+    // The histogram spans exactly the scores present (the survivors of a long candidate list
+    // all sit within a hair of each other, far above the threshold): bins of the smallest
+    // power-of-two width that covers [min, max] in NMS_BINS bins.
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const u32 omn = __shfl_xor(lmin, d), omx = __shfl_xor(lmax, d);
+        lmin = omn < lmin ? omn : lmin;
+        lmax = omx > lmax ? omx : lmax;
+    }
+    if (lane == 0) { s_misc[8 + (t >> 6)] = (int)lmin; s_misc[12 + (t >> 6)] = (int)lmax; }
+    __syncthreads();
+    u32 omin = (u32)s_misc[8], omax = (u32)s_misc[12];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const u32 mn = (u32)s_misc[8 + w], mx = (u32)s_misc[12 + w];
+        omin = mn < omin ? mn : omin;
+        omax = mx > omax ? mx : omax;
+    }
+    int hshift = 0;
+    if (omax >= omin)
+        while (((omax - omin) >> hshift) >= (u32)NMS_BINS) ++hshift;
+    auto bin_of = [&](u64 key) {
+        const u32 bin = ((u32)(key >> 32) - omin) >> hshift;
+        return bin < (u32)NMS_BINS ? (int)bin : NMS_BINS - 1;
+    };
+    for (int i = t; i < npow2; i += 256) {
+        const u64 key = keys[i];
+        if (key != 0) atomicAdd(&hist[bin_of(key)], 1);
     }
     __syncthreads();
     hist_cut(hist, a.total, t, s_misc, s_misc + 4);
@@ -354,7 +447,7 @@ int launch_nms(const NmsArgs &a, hipStream_t s) {
     if (rc) return rc;
     int npow2 = 256;
     while (npow2 < a.C * a.per_class) npow2 <<= 1;
-    const size_t merge_lds = (size_t)npow2 * 16 + NMS_BINS * 4 + 32;
+    const size_t merge_lds = (size_t)npow2 * 16 + NMS_BINS * 4 + 64;
     if (merge_lds > 64 * 1024) {
         if (merge_lds > 160 * 1024) return fail(YMX_EUNSUPPORTED, "nms: C * per_class = %d too large", a.C * a.per_class);
         static LdsReserve reserved;

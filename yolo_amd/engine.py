@@ -403,21 +403,23 @@ class Detector(nn.Module):
         return plan.heads
 
     def _postprocess_part(self, part, image_size):
-        L = _lib.lib()
+        self._decode_part(part, image_size)
+        self._nms_part(part)
+
+    def _decode_part(self, part, image_size):
         sc = part.scales
-        B, C = part.B, self.num_classes
+        _lib.launch("ymx_decode_filter_strided", part.boxes, sc.ptrs, sc.cell_ld, sc.n, sc.S, part.B, self.num_classes,
+                    _lib.dtype_code(part.head_dtype), sc.anchors, sc.strides, sc.xyscale, 1, float(self.score_threshold),
+                    float(image_size), _lib.ptr(part.boxes), _lib.ptr(part.scores_cm), _lib.ptr(part.src_idx),
+                    _lib.ptr(part.counts), part.cap, _lib.ptr(part.dec_ws), part.dec_ws_bytes)
+
+    def _nms_part(self, part):
         out_boxes, out_scores, out_classes, out_valid, out_keep = part.out
-        _lib.launch("ymx_decode_filter_strided", part.boxes, sc.ptrs, sc.cell_ld, sc.n, sc.S, B, C, _lib.dtype_code(part.head_dtype),
-                                               sc.anchors, sc.strides, sc.xyscale, 1, float(self.score_threshold),
-                                               float(image_size), _lib.ptr(part.boxes), _lib.ptr(part.scores_cm),
-                                               _lib.ptr(part.src_idx), _lib.ptr(part.counts), part.cap,
-                                               _lib.ptr(part.dec_ws), part.dec_ws_bytes)
         _lib.launch("ymx_nms_combined", part.boxes, _lib.ptr(part.boxes), _lib.ptr(part.scores_cm), _lib.ptr(part.counts),
-                                      _lib.ptr(part.src_idx), B, part.cap, C, int(self.max_outputs_per_class),
-                                      int(self.max_outputs), float(self.iou_threshold), float(self.score_threshold),
-                                      _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_classes),
-                                      _lib.ptr(out_valid), _lib.ptr(out_keep), _lib.ptr(part.nms_ws),
-                                      part.nms_ws_bytes)
+                    _lib.ptr(part.src_idx), part.B, part.cap, self.num_classes, int(self.max_outputs_per_class),
+                    int(self.max_outputs), float(self.iou_threshold), float(self.score_threshold),
+                    _lib.ptr(out_boxes), _lib.ptr(out_scores), _lib.ptr(out_classes), _lib.ptr(out_valid),
+                    _lib.ptr(out_keep), _lib.ptr(part.nms_ws), part.nms_ws_bytes)
 
     def check_status(self):
         """Synchronises and raises if any decode+filter launch of this detector's plans left
