@@ -1,6 +1,7 @@
-"""In-kernel timeline of the decode+filter kernel on the NMS-stress heads (tuning aid).
+"""In-kernel timelines of the decode+filter kernel and of the per-class NMS kernel on the
+NMS-stress heads (tuning aid).
 
-    make -C yolo_amd/csrc stamps && python tools/stamp_decode.py [batch]
+    make -C yolo_amd/csrc stamps && python tools/stamp_decode.py [batch] [detector]
 
 Prints, per interval of a workgroup's life, the median / p10 / p90 over the stamped
 workgroups in microseconds (100 MHz wall clock).
@@ -24,13 +25,16 @@ NBLK = 16384
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    stress = len(sys.argv) <= 2 or sys.argv[2] != "detector"
     C = 80
     g = torch.Generator().manual_seed(10)
     heads = []
-    for S in (160, 80, 40):
+    for S in ((160, 80, 40) if stress else (52, 26, 13)):
         h = torch.randn(B, S, S, 3, 5 + C, generator=g) * 2
-        h[..., 4] += 6.0
+        if stress:
+            h[..., 4] += 6.0
         heads.append(h.cuda())
+    thr, size = (0.001, 1280.0) if stress else (0.25, 416.0)
     cfg = Y.config
     handle = ctypes.CDLL(_lib.LIB_PATH)
     reader = handle.ymx_debug_stamps_decode
@@ -38,18 +42,38 @@ def main():
     reader.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     for _ in range(3):
         r = U.decode_heads(heads, C, cfg["strides"], cfg["xyscale"], U.default_anchors(), filter=True,
-                           score_threshold=0.001, image_size=1280.0)
+                           score_threshold=thr, image_size=size)
     torch.cuda.synchronize()
     buf = np.zeros((NBLK, 8), dtype=np.uint64)
     assert reader(buf.ctypes.data, buf.nbytes) == 0
     s = buf[buf[:, 0] != 0].astype(np.int64)
     names = ["wait for rows", "compute + ballot", "publish, next rows, look-back", "stores", "iteration"]
-    print("%d workgroups stamped at their 11th segment" % s.shape[0])
-    for i in range(5):
+    print("mean survivors per image %.0f" % float(r["counts"].float().mean()))
+    print("%d workgroups stamped at their 4th segment" % s.shape[0])
+    for i in range(5 if s.shape[0] else 0):
         d = (s[:, i + 1] - s[:, i]) if i < 4 else (s[:, 4] - s[:, 0])
         d = d / 100.0
         print("  %-18s median %7.2f  p10 %7.2f  p90 %7.2f us" % (names[i], np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
-    print("  span of the stamped iterations %.1f us" % ((s[:, 4].max() - s[:, 0].min()) / 100.0))
+    if s.shape[0]:
+        print("  span of the stamped iterations %.1f us" % ((s[:, 4].max() - s[:, 0].min()) / 100.0))
+    # per-class NMS kernel on the decoded result
+    from yolo_amd import utils as UU
+    for _ in range(2):
+        UU.nms_class_major(r["boxes"], r["scores_cm"], r["counts"], r["src_idx"], 32, 32, 0.45, thr)
+    torch.cuda.synchronize()
+    reader = handle.ymx_debug_stamps_nms
+    reader.restype = ctypes.c_int
+    reader.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    buf = np.zeros((NBLK, 8), dtype=np.uint64)
+    assert reader(buf.ctypes.data, buf.nbytes) == 0
+    s = buf[buf[:, 0] != 0].astype(np.int64)
+    names = ["sampled histogram pass", "floor + key pass", "sort", "greedy", "total"]
+    print("nms_class_kernel: %d workgroups" % s.shape[0])
+    for i in range(5):
+        d = (s[:, i + 1] - s[:, i]) if i < 4 else (s[:, 4] - s[:, 0])
+        d = d / 100.0
+        print("  %-24s median %7.2f  p10 %7.2f  p90 %7.2f us" % (names[i], np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+    print("  kernel span %.1f us" % ((s[:, 4].max() - s[:, 0].min()) / 100.0))
 
 
 if __name__ == "__main__":

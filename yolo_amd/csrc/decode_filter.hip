@@ -1,21 +1,30 @@
 // Head decode, score threshold and order-preserving compaction for gfx950.
 //
-// One launch handles every scale and every image.  A workgroup of 256 threads owns a
-// *segment* of 256 consecutive candidates of one scale of one image and walks it in
-// four sub-steps of 64 candidates.  Per sub-step the 64 rows of (5+C) logits, which
-// are contiguous in memory, are copied to LDS with coalesced 16-byte loads; then
-// wave q (one lane per candidate) evaluates class slice q, so LDS is read at a row
-// stride of 5+C words (odd for C = 80: conflict-free) and the class-major score
-// matrix is written with one 4-byte element per lane to consecutive addresses.
+// One launch handles every scale and every image.  A *segment* is 64 consecutive candidates
+// of one scale of one image.  Workgroups of 256 threads are persistent: blockIdx.x is the
+// image, and the workgroups of an image take its segments one after another by ticket.  The
+// 64 rows of (5+C) logits of a segment, contiguous in memory, go to LDS (fp32 maps: by
+// LDS-DMA, no registers involved); wave q (one lane per candidate) evaluates class slice q,
+// so LDS is read at a row stride of 5+C words (odd for C = 80: conflict-free) and the
+// class-major score matrix is written with one 4-byte element per lane to consecutive
+// addresses.
 //
-// Compaction: each candidate's max score is reduced over the four class slices
-// through LDS, a wavefront ballot turns the 64 keep flags into a bit mask, and a
-// survivor's slot is  segment base + survivors in earlier sub-steps + popcount of
-// the mask below its lane.  Segment bases come from a decoupled look-back over
-// 8-byte {status, count} words (one relaxed agent-scope store / load each, so a
-// word is never torn and needs no fence).  Segments are handed out by a per-image
-// ticket, so every predecessor of a waiting segment is already running; spins are
-// bounded and raise an error word instead of hanging.
+// Compaction: each candidate's max score is reduced over the four class slices through LDS,
+// a wavefront ballot turns the 64 keep flags into a bit mask, and a survivor's slot is
+// segment base + popcount of the mask below its lane.  Segment bases come from a decoupled
+// look-back over 8-byte {status, count} words (one relaxed agent-scope store / load each, so
+// a word is never torn and needs no fence), read a window of 64 predecessors at a time by
+// wave 0.  Tickets are drawn per image in increasing order, so every predecessor of a waiting
+// segment is already being worked on; spins are bounded and raise an error word instead of
+// hanging.
+//
+// The loop is software-pipelined around the two round trips that would otherwise idle the
+// CU's LDS: a segment's count is published as soon as it is known; then wave 1 draws the next
+// ticket and starts that segment's rows towards LDS; and the look-back and the stores are
+// those of the PREVIOUS segment, whose predecessors published an iteration ago (its scores
+// wait in registers).  Measured on 32 x 100 800 candidates, 80 classes: 0.61 ms for the
+// one-segment-per-workgroup form with a serial look-back, 0.51 ms for this one; without any
+// look-back the same traffic takes 0.42 ms, the reads alone 0.21 ms.
 //
 // Algorithmic bytes: N*(5+C)*e read once, M*(4+C+1)*4 written once.
 #include "lds_dma.h"
@@ -30,7 +39,7 @@ typedef unsigned long long u64;
 #define DSTAMP(k)                                                                               \
     do {                                                                                        \
         const unsigned lin_ = blockIdx.x + gridDim.x * blockIdx.y;                              \
-        if (threadIdx.x == 0 && lin_ < YMX_STAMP_BLOCKS && dstamp_it == 10) ymx_stamp_buf[lin_ * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        if (threadIdx.x == 0 && lin_ < YMX_STAMP_BLOCKS && dstamp_it == 3) ymx_stamp_buf[lin_ * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 #else
 #define DSTAMP(k) do { } while (0)

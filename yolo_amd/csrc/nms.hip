@@ -1,39 +1,52 @@
 // Combined (per-class, then per-image top-k) non-maximum suppression for gfx950.
 //
 // Kernel 1, one workgroup per (class, image): streams the class's score row (the
-// score matrix is class-major, so the row is contiguous: coalesced 16-byte loads,
-// every score byte read once) and selects candidates in exact (score desc, index
-// asc) order without sorting the row:
+// score matrix is class-major, so the row is contiguous: coalesced 16-byte loads) and
+// selects candidates in exact (score desc, index asc) order without sorting the row:
 //   - every candidate is a 64-bit key  ord(score) << 32 | ~index,  so one unsigned
 //     compare gives the visiting order;
-//   - a first pass over the row builds a 1024-bin histogram of the candidates' score
-//     bits (LDS atomics); a suffix sum over it gives the highest bin edge above which
-//     at least 8 * per_class candidates lie, and that edge is the starting floor: the
-//     greedy pass rarely needs more than a few times per_class candidates, so most of
-//     a long row is never stored or sorted;
-//   - a second pass appends the keys above the score threshold and the floor to an
-//     LDS buffer (wavefront ballot + one LDS atomic per wave);  should the buffer
-//     still fill up (many equal scores in one bin) it is bitonic-sorted, cut to its
-//     best 512 keys, and the 512th key becomes the new floor.  At the end the buffer
-//     holds exactly the keys >= floor, sorted;
-//   - wave 0 then runs the greedy suppression over that list in batches of 64: a
-//     lane tests its candidate against every box kept so far (the kept boxes live
-//     one per lane in registers and are broadcast with readlane), a ballot gives
-//     the bit mask of still-alive lanes, and the mask is resolved leader by leader;
-//   - if the list runs out before per_class boxes are kept and keys were left out, the
-//     scan repeats below the last visited key (a further tier).  The result is the
-//     exact greedy NMS for any input; floor and tiers only matter for speed.
-// Kernel 2, one workgroup per image: bitonic-sorts the kept entries of all classes
-// by (score desc, class asc, index asc) in LDS and writes the first `total`.
+//   - a first pass over a SAMPLE of the row (every k-th 1024-candidate chunk, k up to 8)
+//     builds a 1024-bin histogram of the candidates' score bits (LDS atomics); a suffix sum
+//     gives the highest bin edge above which the sample holds its share of 4 * per_class
+//     candidates plus three standard deviations, and that edge is the starting floor;
+//   - a second pass appends the keys above the score threshold and the floor to an LDS
+//     buffer (wavefront ballot + one LDS atomic per wave, no barrier inside the loop).  Should
+//     the buffer overflow (many equal scores in one bin) the pass is repeated in a careful
+//     form that sorts and cuts the buffer whenever it could fill up;
+//   - the buffer's few hundred keys are not sorted as a whole: a second histogram over
+//     exactly the scores present picks the best 3 * per_class or so, those are sorted by
+//     rank and visited; if they do not yield per_class boxes the next group follows;
+//   - wave 0 runs the greedy suppression in batches of 64: a lane tests its candidate
+//     against every box kept so far (the kept boxes live one per lane in registers and are
+//     broadcast with readlane), a ballot gives the bit mask of still-alive lanes, and the
+//     mask is resolved leader by leader;
+//   - if the buffer runs out before per_class boxes are kept and keys were left out, the
+//     scan repeats below the last visited key with twice the target (a further tier).  The
+//     result is the exact greedy NMS for any input; floor, sample and tiers only matter for
+//     speed.
+// Kernel 2, one workgroup per image: cuts the kept entries of all classes with a histogram
+// spanning their scores, sorts the survivors of the cut by (score desc, class asc, index asc)
+// in LDS and writes the first `total`.
 //
 // IoU arithmetic is fp32, in a fixed order, compiled without contraction, with a
 // correctly rounded division, so keep decisions are reproducible bit for bit.
 #include <atomic>
 #include <cstring>
 
-#include "common.h"
+#include "lds_dma.h"
 
 namespace ymx {
+
+// Diagnostic build only (make stamps): the 100 MHz wall clock at points of a workgroup's life.
+#ifdef YMX_STAMPS
+#define NSTAMP(k)                                                                               \
+    do {                                                                                        \
+        const unsigned lin_ = blockIdx.x + gridDim.x * blockIdx.y;                              \
+        if (threadIdx.x == 0 && lin_ < YMX_STAMP_BLOCKS) ymx_stamp_buf[lin_ * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define NSTAMP(k) do { } while (0)
+#endif
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
@@ -67,7 +80,11 @@ __device__ __forceinline__ void bitonic_desc(u64 *buf, int n, int t) {
     }
 }
 
-// true iff IoU(a, b) > thr.  Boxes are normalised (min corner first); areas given.
+// true iff IoU(a, b) > thr, where IoU is the correctly rounded quotient inter / union (the
+// arithmetic of the oracle).  Boxes are normalised (min corner first); areas given.  The
+// division is only carried out when the products cannot decide: inter and thr * union further
+// apart than a few ulps give the same answer as the rounded quotient (a correctly rounded
+// quotient is within half an ulp of the true one, the product within half an ulp of its own).
 __device__ __forceinline__ bool iou_gt(float ay1, float ax1, float ay2, float ax2, float aar,
                                        float by1, float bx1, float by2, float bx2, float bar, float thr) {
     if (!(aar > 0.0f) || !(bar > 0.0f)) return false;
@@ -75,7 +92,39 @@ __device__ __forceinline__ bool iou_gt(float ay1, float ax1, float ay2, float ax
     const float iy2 = fminf(ay2, by2), ix2 = fminf(ax2, bx2);
     const float inter = fmaxf(iy2 - iy1, 0.0f) * fmaxf(ix2 - ix1, 0.0f);
     const float uni = (aar + bar) - inter;
+    const float prod = thr * uni;
+    // |prod - thr*uni| <= 2^-24 |prod| and |fl(inter/uni) - inter/uni| <= 2^-24 |inter/uni|: outside a
+    // relative band of 2^-20 around equality both tests agree; inside it (and for non-finite or
+    // non-positive operands, where the band test is false) the quotient decides
+    const float band = 9.5367431640625e-07f * fabsf(prod);
+    if (prod > 1e-30f) {                       // normal range only (uni > 0 and thr > 0 follow)
+        if (inter > prod + band) return true;
+        if (inter < prod - band) return false;
+    }
     return (inter / uni) > thr;
+}
+
+// Descending sort of n keys (all different, zero = padding allowed only as ties at the end)
+// by rank: every thread counts, for each key it owns, the keys greater than it -- n
+// broadcast reads of LDS, no barrier inside -- and writes the key to its rank in `out`.
+// For a few hundred keys this is several times quicker than a sorting network, whose every
+// stage ends in a barrier.
+__device__ __forceinline__ void rank_sort_desc(const u64 *in, u64 *out, int n, int t) {
+    // in[n .. n8) must be zero (n8 = n rounded up to 8): the scan reads eight keys per step
+    const int n8 = (n + 7) & ~7;
+    const ulonglong2 *in2 = (const ulonglong2 *)in;
+    for (int i0 = 0; i0 < n; i0 += 512) {
+        const int ia = i0 + t, ib = i0 + 256 + t;
+        const u64 ka = ia < n ? in[ia] : ~0ull, kb = ib < n ? in[ib] : ~0ull;
+        int ra = 0, rb = 0;
+        for (int j = 0; j < n8; j += 8) {
+            const ulonglong2 p0 = in2[(j >> 1)], p1 = in2[(j >> 1) + 1], p2 = in2[(j >> 1) + 2], p3 = in2[(j >> 1) + 3];
+            ra += (p0.x > ka) + (p0.y > ka) + (p1.x > ka) + (p1.y > ka) + (p2.x > ka) + (p2.y > ka) + (p3.x > ka) + (p3.y > ka);
+            rb += (p0.x > kb) + (p0.y > kb) + (p1.x > kb) + (p1.y > kb) + (p2.x > kb) + (p2.y > kb) + (p3.x > kb) + (p3.y > kb);
+        }
+        if (ia < n) out[ra] = ka;
+        if (ib < n) out[rb] = kb;
+    }
 }
 
 // Suffix scan of a 1024-bin histogram by 256 threads: returns (through *s_cutbin, which
@@ -111,13 +160,14 @@ __device__ __forceinline__ float4 load_chunk(const float *__restrict__ col, int 
     return i0 < M ? *(const float4 *)(col + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 6)
 nms_class_kernel(const NmsArgs a) {
-    __shared__ u64 buf[NMS_BUF];
+    __shared__ __attribute__((aligned(16))) u64 buf[NMS_BUF + 8];
     __shared__ int hist[NMS_BINS];
     __shared__ int s_wsum[4];
-    __shared__ u64 s_last;
-    __shared__ int s_cnt, s_nkept, s_cutbin;
+    __shared__ u64 s_last, s_last2, s_kmin[4];
+    __shared__ u32 s_red[8];
+    __shared__ int s_cnt, s_cnt2, s_nkept, s_cutbin;
 
     const int c = blockIdx.x, b = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63;
@@ -136,7 +186,9 @@ nms_class_kernel(const NmsArgs a) {
         const u32 range = (a.score_thr < 1.0f) ? ord_bits(1.0f) - ob_thr : (1u << 23);
         while ((range >> hshift) >= (u32)NMS_BINS) ++hshift;
     }
-    int target = 8 * PC;
+    // candidates wanted above the floor: four times what may be kept (the greedy pass seldom
+    // visits more before per_class boxes stand); every further tier doubles it
+    int target = 4 * PC;
     target = target < 64 ? 64 : (target > NMS_KEEP ? NMS_KEEP : target);
 
     // The floor comes from a SAMPLE of the row: every k-th chunk (k grows with the row, up to
@@ -148,11 +200,6 @@ nms_class_kernel(const NmsArgs a) {
     const int nchunk = (M + NMS_CHUNK - 1) / NMS_CHUNK;
     int kstep = nchunk / 4;
     kstep = kstep < 1 ? 1 : (kstep > 8 ? 8 : kstep);
-    int starget = target;
-    if (kstep > 1) {
-        const float share = (float)target / (float)kstep;
-        starget = (int)(share + 3.0f * sqrtf(share)) + 4;
-    }
 
     // wave 0: kept box j lives in lane j
     float ky1 = 0.f, kx1 = 0.f, ky2 = 0.f, kx2 = 0.f, kar = 0.f;
@@ -160,8 +207,14 @@ nms_class_kernel(const NmsArgs a) {
     int nkept = 0;
     u64 ceil_key = ~0ull;           // keys must be < ceil_key
 
+    NSTAMP(0);
     for (;;) {   // one pass per tier
         // ---- starting floor: the highest bin edge with at least `starget` sampled candidates above it
+        int starget = target;
+        if (kstep > 1) {
+            const float share = (float)target / (float)kstep;
+            starget = (int)(share + 3.0f * sqrtf(share)) + 4;
+        }
         for (int i = t; i < NMS_BINS; i += 256) hist[i] = 0;
         if (t == 0) { s_cnt = 0; s_cutbin = 0; }
         __syncthreads();
@@ -187,6 +240,7 @@ nms_class_kernel(const NmsArgs a) {
             }
         }
         __syncthreads();
+        NSTAMP(1);
         hist_cut(hist, starget, t, s_wsum, &s_cutbin);
         const int cutbin = s_cutbin;   // 0: fewer than `starget` sampled candidates in all, take everything
         u64 floor_key = cutbin > 0 ? (((u64)(ob_thr + ((u32)cutbin << hshift))) << 32) - 1ull : 0ull;   // keys must be > floor_key
@@ -196,15 +250,10 @@ nms_class_kernel(const NmsArgs a) {
         // appended (ballot + one LDS atomic per wave); positions beyond the buffer are counted
         // but not stored, and if that happened the pass is repeated in the careful form below.
         {
-            float4 nxt[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) nxt[u] = load_chunk(col, u * NMS_CHUNK + t * 4, M);
             for (int j0 = 0; j0 < nchunk; j0 += 4) {
-                float4 v[4];
+                float4 v[4];                               // four independent loads in flight per thread
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = nxt[u];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) nxt[u] = load_chunk(col, (j0 + 4 + u) * NMS_CHUNK + t * 4, M);
+                for (int u = 0; u < 4; ++u) v[u] = load_chunk(col, (j0 + u) * NMS_CHUNK + t * 4, M);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int i0 = (j0 + u) * NMS_CHUNK + t * 4;
@@ -229,6 +278,7 @@ nms_class_kernel(const NmsArgs a) {
             }
         }
         __syncthreads();
+        NSTAMP(2);
         if (s_cnt > NMS_BUF) {
             // ---- careful form: capacity checked after every chunk; when the buffer could
             // overflow it is sorted, cut to its best NMS_KEEP keys and the floor is raised
@@ -272,17 +322,13 @@ nms_class_kernel(const NmsArgs a) {
             }
         }
         const int n = s_cnt;
-        int nsort = 64;
-        while (nsort < n) nsort <<= 1;
-        for (int i = n + t; i < nsort; i += 256) buf[i] = 0;
-        __syncthreads();
-        bitonic_desc(buf, nsort, t);
-
-        if (t < 64) {
-            for (int base = 0; base < n && nkept < PC; base += 64) {
+        // wave 0: greedy suppression over `cnt` keys in visiting order; kept boxes accumulate in
+        // the lanes of wave 0 across calls
+        auto greedy = [&](const u64 *sorted, int cnt) {
+            for (int base = 0; base < cnt && nkept < PC; base += 64) {
                 const int e = base + lane;
-                const bool valid = e < n;
-                const u64 key = valid ? buf[e] : 0ull;
+                const bool valid = e < cnt;
+                const u64 key = valid ? sorted[e] : 0ull;
                 const u32 idx = 0xffffffffu - (u32)key;
                 float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (valid) bx = boxes4[idx];
@@ -312,15 +358,124 @@ nms_class_kernel(const NmsArgs a) {
                     m = __ballot(alive);
                 }
             }
-            if (t == 0) {
-                s_nkept = nkept;
-                s_last = n > 0 ? buf[n - 1] : 0ull;
+        };
+
+        if (n > 0 && n <= NMS_BUF / 2 - 8) {
+            // ---- the usual case.  The buffer holds a few hundred unsorted keys (a histogram bin is
+            // coarse next to the few dozen keys the greedy pass will visit), so they are not sorted
+            // as a whole: a second histogram, spanning exactly the scores in the buffer, picks the
+            // best `t2` or so, only those are sorted (by rank) and visited; if that does not yield
+            // per_class boxes the next best group below them follows, all inside LDS.
+            u64 *sel = buf + NMS_BUF / 2;                  // [<= 1024] selection, its sorted copy behind it
+            const int t2 = PC < 22 ? 64 : 3 * PC;
+            u64 lceil = ~0ull;                             // this group's keys are < lceil
+            for (;;) {
+                u32 lmin = 0xffffffffu, lmax = 0u;
+                u64 kmin = ~0ull;
+                for (int i = t; i < n; i += 256) {
+                    const u64 k = buf[i];
+                    kmin = k < kmin ? k : kmin;
+                    if (k < lceil) {
+                        const u32 o = (u32)(k >> 32);
+                        lmin = o < lmin ? o : lmin;
+                        lmax = o > lmax ? o : lmax;
+                    }
+                }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    const u32 omn = __shfl_xor(lmin, d), omx = __shfl_xor(lmax, d);
+                    const u32 klo = __shfl_xor((u32)kmin, d), khi = __shfl_xor((u32)(kmin >> 32), d);
+                    const u64 ok = ((u64)khi << 32) | klo;
+                    lmin = omn < lmin ? omn : lmin;
+                    lmax = omx > lmax ? omx : lmax;
+                    kmin = ok < kmin ? ok : kmin;
+                }
+                for (int i = t; i < NMS_BINS; i += 256) hist[i] = 0;
+                if (lane == 0) { s_red[t >> 6] = lmin; s_red[4 + (t >> 6)] = lmax; s_kmin[t >> 6] = kmin; }
+                if (t == 0) { s_cnt2 = 0; s_cutbin = 0; }
+                __syncthreads();
+                u32 omin = s_red[0], omax = s_red[4];
+                kmin = s_kmin[0];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    omin = s_red[w] < omin ? s_red[w] : omin;
+                    omax = s_red[4 + w] > omax ? s_red[4 + w] : omax;
+                    kmin = s_kmin[w] < kmin ? s_kmin[w] : kmin;
+                }
+                if (omax < omin) {                         // nothing left below lceil: the buffer is used up
+                    if (t == 0) { s_nkept = nkept; s_last = kmin; }   // nkept: wave 0's count
+                    break;
+                }
+                int sh2 = 0;
+                while (((omax - omin) >> sh2) >= (u32)NMS_BINS) ++sh2;
+                for (int i = t; i < n; i += 256) {
+                    const u64 k = buf[i];
+                    if (k < lceil) atomicAdd(&hist[((u32)(k >> 32) - omin) >> sh2], 1);
+                }
+                __syncthreads();
+                hist_cut(hist, t2, t, s_wsum, &s_cutbin);
+                const int cb2 = s_cutbin;                  // 0: fewer than t2 keys left, take them all
+                for (int i0 = 0; i0 < n; i0 += 256) {
+                    const int i = i0 + t;
+                    const u64 k = i < n ? buf[i] : 0ull;
+                    const bool pred = i < n && k < lceil && (int)(((u32)(k >> 32) - omin) >> sh2) >= cb2;
+                    const u64 bal = __ballot(pred);
+                    if (bal) {
+                        const int leader = __ffsll((long long)bal) - 1;
+                        int pos = 0;
+                        if (lane == leader) pos = atomicAdd(&s_cnt2, __popcll(bal));
+                        pos = __shfl(pos, leader);
+                        if (pred) sel[pos + __popcll(bal & below)] = k;
+                    }
+                }
+                __syncthreads();
+                const int nsel = s_cnt2;
+                const u64 *sorted;
+                if (nsel <= 500) {
+                    if (t < 8) sel[nsel + t] = 0;          // the rank scan's padding
+                    __syncthreads();
+                    rank_sort_desc(sel, sel + 512, nsel, t);
+                    sorted = sel + 512;
+                } else {
+                    int nsort = 512;
+                    while (nsort < nsel) nsort <<= 1;
+                    for (int i = nsel + t; i < nsort; i += 256) sel[i] = 0;
+                    __syncthreads();
+                    bitonic_desc(sel, nsort, t);
+                    sorted = sel;
+                }
+                __syncthreads();
+                if (t < 64) {
+                    greedy(sorted, nsel);
+                    if (t == 0) { s_nkept = nkept; s_last = kmin; s_last2 = sorted[nsel - 1]; }
+                }
+                __syncthreads();
+                if (s_nkept >= PC || cb2 == 0) break;      // done, or every key of the buffer visited
+                lceil = s_last2;
+                __syncthreads();
+            }
+        } else {
+            // ---- a buffer more than half full (many equal scores): sort all of it
+            int nsort = 64;
+            while (nsort < n) nsort <<= 1;
+            for (int i = n + t; i < nsort; i += 256) buf[i] = 0;
+            __syncthreads();
+            bitonic_desc(buf, nsort, t);
+            if (t < 64) {
+                greedy(buf, n);
+                if (t == 0) {
+                    s_nkept = nkept;
+                    s_last = n > 0 ? buf[n - 1] : 0ull;
+                }
             }
         }
+        NSTAMP(3);
         __syncthreads();
+        NSTAMP(4);
         const int nk = s_nkept;
         if (nk >= PC || !cut || n == 0) break;
         ceil_key = s_last;
+        target = target * 2 > NMS_KEEP ? NMS_KEEP : target * 2;
         __syncthreads();
     }
     if (t < 64) {
@@ -537,3 +692,5 @@ extern "C" int ymx_nms_combined_static(const float *boxes, const float *scores, 
     return nms_entry(boxes, scores, counts, src_idx, B, cap, C, per_class, total, iou_thr, score_thr, out_boxes,
                      out_scores, out_classes, out_valid, out_keep_idx, ws, need, (hipStream_t)stream);
 }
+
+YMX_STAMP_EXPORT(ymx_debug_stamps_nms)
