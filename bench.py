@@ -204,7 +204,7 @@ def stress_workload(args, dev):
                                % (B, 5 + C, N, C),
                    "batch": B, "candidates_per_image": N, "num_classes": C, "mean_survivors_per_image": m_mean,
                    "mean_valid_detections": float(outs[3].float().mean().item())},
-        "roofline": hbm_roofline("decode_kernel<float, 20, 1>", dec_b, dec_ms, pmc_traffic(None, pat, "decode_kernel<float, 20, 1>")),
+        "roofline": hbm_roofline("decode_kernel<float, 20, 1, true>", dec_b, dec_ms, pmc_traffic(None, pat, "decode_kernel<float, 20, 1, true>")),
         "roofline_nms": hbm_roofline("nms_class_kernel + nms_merge_kernel", nms_b, nms_ms, _sum_traffic(pat, ("nms_",))),
     }
     if not args.no_cpu_baseline:
@@ -444,8 +444,8 @@ def main():
         dec_bytes, nms_bytes = postproc_bytes(B, N, C, m_mean, 4)
         # the bandwidth-bound half of the path, on the same line the driver keeps
         line["roofline"]["hbm"] = {
-            "decode": hbm_roofline("decode_kernel<float, 20, 1>", dec_bytes, dec_ms,
-                                   pmc_traffic(None, kernel="decode_kernel<float, 20, 1>")),
+            "decode": hbm_roofline("decode_kernel<float, 20, 1, true>", dec_bytes, dec_ms,
+                                   pmc_traffic(None, kernel="decode_kernel<float, 20, 1, true>")),
             "nms": hbm_roofline("nms_class_kernel + nms_merge_kernel", nms_bytes, nms_ms,
                                 _sum_traffic("r*_pmc_traffic.json", ("nms_",)))}
         line["breakdown"] = {

@@ -243,6 +243,34 @@ int ymx_nms_combined_static(const float *boxes, const float *scores, const int *
 int ymx_affine_act(const void *x, const float *scale, const float *shift, void *y,
                    long long n_pix, int C, int act, int dtype, void *stream);
 
+/* ---- SPP block ---------------------------------------------------------------
+ * Replaces the three tf.nn.max_pool(ksize = 13 / 9 / 5, strides = 1, padding = 'SAME') and
+ * the tf.concat around them in CSPDarknet53.call (backbones.py:254-259):
+ *   y[..., 0:C] = maxpool13(x), y[..., C:2C] = maxpool9(x), y[..., 2C:3C] = maxpool5(x),
+ *   y[..., 3C:4C] = x          (padding never wins a max, as in TensorFlow).
+ * x [B,H,W,C], y [B,H,W,4C], dense; H*W <= 2048. */
+int ymx_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dtype, void *stream);
+
+/* ---- YOLO loss of one scale, forward -----------------------------------------
+ * Replaces yolo_loss (losses.py:10-46) as the closures of get_yolo_loss_at_scales call it
+ * (losses.py:52-66): GIoU loss * (2 - w*h/input_size^2) on responsible cells, focal-weighted
+ * objectness cross-entropy on responsible cells and on background cells whose best IoU
+ * with any ground-truth box is below iou_loss_threshold, class cross-entropy on responsible
+ * cells; each summed per image and averaged over the batch.
+ *   conv   [B,S,S,3,5+C] fp32 raw head map (cell stride conv_ld elements, 0 = dense)
+ *   pred   NULL: the decode of conv (decode_train, utils.py:107-131, with stride, xyscale and
+ *          the scale's three anchors [3][2], host) is computed inside; else [B,S,S,3,5+C] fp32
+ *          dense, of which (cx,cy,w,h,conf) are read, as yolo_loss takes it
+ *   label  [B,S,S,3,5+C] fp32 dense (xywh, respond, class probabilities)
+ *   bboxes [B,n_boxes,4] fp32 (cx,cy,w,h), unused slots zero (128 in the reference)
+ *   out    [3] = (giou_loss, conf_loss, prob_loss); per_image [B][3] per-image sums or NULL
+ * input_size = S * stride (losses.py:56).  Deterministic (no float atomics). */
+size_t ymx_yolo_loss_workspace_bytes(int B, int S);
+int ymx_yolo_loss(const float *conv, int conv_ld, const float *pred, const float *label,
+                  const float *bboxes, int B, int S, int C, int n_boxes, float stride, float xyscale,
+                  const float *anchors /* host */, float iou_loss_threshold, float *out,
+                  float *per_image, void *workspace, size_t ws_bytes, void *stream);
+
 /* ---- box IoU ----------------------------------------------------------------
  * Replaces bbox_iou (utils.py:33-63) and, with giou != 0, bbox_giou
  * (utils.py:65-105) on n pairs of centre-format (cx,cy,w,h) fp32 boxes that the

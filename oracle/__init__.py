@@ -21,6 +21,7 @@ postproc_np   numpy fp32: decode / decode_train / decode_predict /
 net_torch     torch-CPU fp32: YOLOConv / ResidialBlock / Upsample /
               Darknet53 / YoloV3 (layers.py:17-106, backbones.py:6-60,
               detectors.py:4-77)
+loss_np       numpy fp32: yolo_loss / get_yolo_loss_at_scales (losses.py:10-70)
 c/            plain-C restatement of decode / filter / NMS, loaded through
               ctypes by ``oracle.cref``
 """

@@ -1,0 +1,72 @@
+"""GPU parity of the kernels beyond plain inference: the YOLO loss (forward) and the SPP
+max-pool block, called through the C ABI (via the Python mirrors), against the CPU oracle.
+fp32 tolerance 1e-3 relative on every loss term; max-pooling is exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import loss_np as LN
+from oracle import postproc_np as P
+from tests_support import loss_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("S,C,scale,B", [(13, 80, 2, 3), (26, 80, 1, 2), (52, 80, 0, 2), (13, 1, 2, 4), (52, 1, 0, 1),
+                                         (7, 3, 1, 2)])
+def test_yolo_loss_vs_oracle(S, C, scale, B):
+    import yolo_amd as Y
+    from yolo_amd import losses as L
+    conv, label, bboxes = loss_case(B, S, C, scale, seed=100 + S + C, n_gt=6)
+    pred = P.decode_train(conv, scale, S, C)
+    want = np.array(LN.yolo_loss(pred, conv, label, bboxes, S * P.STRIDES[scale], 0.5), np.float64)
+    cfg = Y.config
+    target = np.concatenate([label.reshape(B, -1), bboxes.reshape(B, -1)], axis=1)
+    t_d = torch.from_numpy(target).to(DEV)
+    o_d = torch.from_numpy(conv.reshape(B, S, S, -1)).to(DEV)
+    # the closure path: decode fused into the kernel
+    got = L.loss_at_scale(t_d, o_d, scale, C, cfg["strides"], 0.5, cfg["xyscale"], cfg["anchors"], terms=True)
+    np.testing.assert_allclose(got.cpu().numpy().astype(np.float64), want, rtol=1e-3)
+    fs = L.get_yolo_loss_at_scales([0, 1, 2], C, cfg["strides"], 0.5, cfg["xyscale"], cfg["anchors"])
+    total = fs[2 - scale](t_d, o_d)                      # list order is scales[::-1]
+    np.testing.assert_allclose(float(total), want.sum(), rtol=1e-3)
+    # the reference's own signature: pred handed in
+    g, c, p = L.yolo_loss(torch.from_numpy(pred).to(DEV), torch.from_numpy(conv).to(DEV), torch.from_numpy(label).to(DEV),
+                          torch.from_numpy(bboxes).to(DEV), S * P.STRIDES[scale], 0.5)
+    np.testing.assert_allclose(np.array([float(g), float(c), float(p)]), want, rtol=1e-3)
+    # reproducible bit for bit
+    again = L.loss_at_scale(t_d, o_d, scale, C, cfg["strides"], 0.5, cfg["xyscale"], cfg["anchors"], terms=True)
+    assert torch.equal(got, again)
+
+
+def test_yolo_loss_late_binding_and_errors():
+    import yolo_amd as Y
+    from yolo_amd import losses as L
+    cfg = Y.config
+    B, S, C = 2, 13, 4
+    conv, label, bboxes = loss_case(B, S, C, 2, seed=5)
+    target = torch.from_numpy(np.concatenate([label.reshape(B, -1), bboxes.reshape(B, -1)], axis=1)).to(DEV)
+    out = torch.from_numpy(conv.reshape(B, S, S, -1)).to(DEV)
+    late = L.get_yolo_loss_at_scales([0, 1, 2], C, cfg["strides"], 0.5, cfg["xyscale"], cfg["anchors"], late_binding=True)
+    want0 = LN.loss_at_scale(target.cpu().numpy(), conv.reshape(B, S, S, -1), 0, C, P.STRIDES, 0.5, P.XYSCALE, P.ANCHORS)[0]
+    for f in late:                                       # the reference's closures all use scales[0]
+        np.testing.assert_allclose(float(f(target, out)), float(want0), rtol=1e-3)
+    with pytest.raises(ValueError):
+        L.loss_at_scale(target[:, :-4], out, 2, C, cfg["strides"], 0.5, cfg["xyscale"], cfg["anchors"])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        L.loss_at_scale(target.cpu(), out.cpu(), 2, C, cfg["strides"], 0.5, cfg["xyscale"], cfg["anchors"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 13, 13, 512), (1, 19, 19, 64), (3, 7, 5, 24), (1, 40, 40, 16), (2, 3, 4, 8)])
+def test_spp_concat_exact(shape, dtype):
+    from yolo_amd.layers import spp_concat
+    B, H, W, C = shape
+    x = torch.randn(B, H, W, C, generator=torch.Generator().manual_seed(H * W + C)).to(dtype)
+    xn = x.float().permute(0, 3, 1, 2)
+    want = torch.cat([F.max_pool2d(xn, k, 1, k // 2) for k in (13, 9, 5)] + [xn], dim=1).permute(0, 2, 3, 1)
+    got = spp_concat(x.to(DEV))
+    assert got.shape == (B, H, W, 4 * C) and got.dtype == dtype
+    assert torch.equal(got.float().cpu(), want)

@@ -275,3 +275,99 @@ def test_conv_goldens(golden_dir):
         if "residual" in g.files:
             y = y + torch.from_numpy(g["residual"])
         np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-4, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- loss
+def _scalar_loss_terms(conv, label, bboxes, scale, S, C, strides, xyscale, anchors, thr):
+    """The loss of /root/reference/losses.py:10-66 spelled out candidate by candidate in
+    plain Python floats (double precision): an independent restatement for small cases."""
+    import math
+    sig = lambda v: 1.0 / (1.0 + math.exp(-v))
+    sce = lambda z, x: max(x, 0.0) - x * z + math.log1p(math.exp(-abs(x)))
+
+    def iou_giou(b1, b2):
+        a1, a2 = b1[2] * b1[3], b2[2] * b2[3]
+        l1, t1, r1, d1 = b1[0] - b1[2] / 2, b1[1] - b1[3] / 2, b1[0] + b1[2] / 2, b1[1] + b1[3] / 2
+        l2, t2, r2, d2 = b2[0] - b2[2] / 2, b2[1] - b2[3] / 2, b2[0] + b2[2] / 2, b2[1] + b2[3] / 2
+        iw, ih = max(min(r1, r2) - max(l1, l2), 0.0), max(min(d1, d2) - max(t1, t2), 0.0)
+        inter = iw * ih
+        union = a1 + a2 - inter
+        iou = inter / union if union != 0 else 0.0
+        ew, eh = max(r1, r2) - min(l1, l2), max(d1, d2) - min(t1, t2)
+        enc = ew * eh
+        return iou, iou - ((enc - union) / enc if enc != 0 else 0.0)
+
+    B = conv.shape[0]
+    input_size = S * strides[scale]
+    tot = [0.0, 0.0, 0.0]
+    for b in range(B):
+        for r in range(S):
+            for c in range(S):
+                for a in range(3):
+                    t = [float(v) for v in conv[b, r, c, a]]
+                    lab = [float(v) for v in label[b, r, c, a]]
+                    xs, st = xyscale[scale], strides[scale]
+                    px = (sig(t[0]) * xs - 0.5 * (xs - 1) + c) * st
+                    py = (sig(t[1]) * xs - 0.5 * (xs - 1) + r) * st
+                    pw = math.exp(t[2]) * float(anchors[scale][a][0])
+                    ph = math.exp(t[3]) * float(anchors[scale][a][1])
+                    pconf = sig(t[4])
+                    respond = lab[4]
+                    _, giou = iou_giou((px, py, pw, ph), lab[:4])
+                    tot[0] += respond * (2.0 - lab[2] * lab[3] / input_size ** 2) * (1 - giou)
+                    best = max(iou_giou((px, py, pw, ph), [float(v) for v in bboxes[b, j]])[0] for j in range(bboxes.shape[1]))
+                    bgd = (1 - respond) * (1.0 if best < thr else 0.0)
+                    bce = sce(respond, t[4])
+                    tot[1] += (respond - pconf) ** 2 * (respond * bce + bgd * bce)
+                    tot[2] += respond * sum(sce(lab[5 + k], t[5 + k]) for k in range(C))
+    return [v / B for v in tot]
+
+
+from tests_support import loss_case as _loss_case      # noqa: E402
+
+
+def test_loss_oracle_matches_scalar_restatement():
+    from oracle import loss_np as LN
+    for (B, S, C, scale, seed) in ((2, 3, 2, 0, 1), (1, 2, 5, 2, 2), (2, 4, 1, 1, 3)):
+        conv, label, bboxes = _loss_case(B, S, C, scale, seed)
+        pred = P.decode_train(conv, scale, S, C)
+        got = LN.yolo_loss(pred, conv, label, bboxes, S * P.STRIDES[scale], 0.5)
+        want = _scalar_loss_terms(conv, label, bboxes, scale, S, C, P.STRIDES, P.XYSCALE, P.ANCHORS, 0.5)
+        np.testing.assert_allclose(np.array(got, np.float64), np.array(want), rtol=2e-5)
+        assert all(np.isfinite(v) for v in want) and want[1] > 0 and want[2] > 0
+        # the closure body on the flat target layout gives the same total
+        target = np.concatenate([label.reshape(B, -1), bboxes.reshape(B, -1)], axis=1)
+        tot, terms = LN.loss_at_scale(target, conv.reshape(B, S, S, -1), scale, C, P.STRIDES, 0.5, P.XYSCALE, P.ANCHORS)
+        np.testing.assert_allclose(float(tot), sum(want), rtol=2e-5)
+
+
+def test_loss_known_answers():
+    """Hand-derived: one cell, zero logits, no responsible anchor -> only the background
+    objectness term: each of the 3 anchors gives (0 - 0.5)^2 * log 2; with a ground-truth box
+    overlapping an anchor's prediction by IoU >= 0.5 that anchor drops out."""
+    from oracle import loss_np as LN
+    C, S, scale = 1, 1, 2
+    conv = np.zeros((1, 1, 1, 3, 6), np.float32)
+    label = np.zeros_like(conv)
+    bboxes = np.zeros((1, 128, 4), np.float32)
+    pred = P.decode_train(conv, scale, S, C)
+    g, c, p = LN.yolo_loss(pred, conv, label, bboxes, 32, 0.5)
+    assert g == 0 and p == 0
+    np.testing.assert_allclose(c, 3 * 0.25 * np.log(2.0), rtol=1e-6)
+    bboxes[0, 0] = pred[0, 0, 0, 1, :4]                 # exactly anchor 1's predicted box: IoU 1 with it
+    g, c, p = LN.yolo_loss(pred, conv, label, bboxes, 32, 0.5)
+    np.testing.assert_allclose(c, 2 * 0.25 * np.log(2.0), rtol=1e-6)
+    # a responsible anchor whose prediction equals its label: GIoU 1 -> no box loss, objectness (1-0.5)^2 log 2
+    label[0, 0, 0, 1, :4] = pred[0, 0, 0, 1, :4]
+    label[0, 0, 0, 1, 4] = 1.0
+    label[0, 0, 0, 1, 5] = 1.0
+    g, c, p = LN.yolo_loss(pred, conv, label, bboxes, 32, 0.5)
+    np.testing.assert_allclose(g, 0.0, atol=1e-6)
+    np.testing.assert_allclose(p, np.log(2.0), rtol=1e-6)
+    # late binding: every closure of the reference uses scales[0]
+    fs = LN.get_yolo_loss_at_scales([0, 1, 2], C, P.STRIDES, 0.5, P.XYSCALE, P.ANCHORS)
+    fs2 = LN.get_yolo_loss_at_scales([0, 1, 2], C, P.STRIDES, 0.5, P.XYSCALE, P.ANCHORS, late_binding=False)
+    target = np.concatenate([label.reshape(1, -1), bboxes.reshape(1, -1)], axis=1)
+    out = conv.reshape(1, 1, 1, -1)
+    assert fs[0](target, out) == fs[1](target, out) == fs[2](target, out) == fs2[2](target, out)
+    assert fs2[0](target, out) != fs2[2](target, out)

@@ -12,6 +12,7 @@ from .utils import (decode, decode_train, decode_predict, filter_bboxes, bbox_nm
 from . import layers
 from . import backbones
 from . import detectors
+from . import losses
 from . import engine
 from . import dist
 from .engine import Detector

@@ -419,6 +419,32 @@ int ymx_nms_combined(const float *boxes, const float *scores, const int *counts,
                      out_scores, out_classes, out_valid, out_keep_idx, workspace, ws_bytes, (hipStream_t)stream);
 }
 
+int ymx_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dtype, void *stream) {
+    if (!x || !y) return fail(YMX_EARG, "spp_concat: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(YMX_EARG, "spp_concat: non-positive size");
+    if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "spp_concat: dtype %d", dtype);
+    if (C % (dtype == YMX_BF16 ? 8 : 4)) return fail(YMX_EUNSUPPORTED, "spp_concat: channels must be a multiple of %d", dtype == YMX_BF16 ? 8 : 4);
+    if (B > 65535) return fail(YMX_EUNSUPPORTED, "spp_concat: batch above 65535");
+    if (!aligned16(x) || !aligned16(y)) return fail(YMX_EARG, "spp_concat: 16-byte alignment");
+    return launch_spp_concat(x, y, B, H, W, C, dtype, (hipStream_t)stream);
+}
+
+size_t ymx_yolo_loss_workspace_bytes(int B, int S) { return yolo_loss_workspace_bytes(B, S); }
+
+int ymx_yolo_loss(const float *conv, int conv_ld, const float *pred, const float *label, const float *bboxes, int B, int S,
+                  int C, int n_boxes, float stride, float xyscale, const float *anchors, float iou_loss_threshold,
+                  float *out, float *per_image, void *workspace, size_t ws_bytes, void *stream) {
+    if (!conv || !label || !bboxes || !anchors || !out) return fail(YMX_EARG, "yolo_loss: null pointer");
+    if (B <= 0 || S <= 0 || C <= 0 || n_boxes <= 0) return fail(YMX_EARG, "yolo_loss: non-positive size");
+    if (B > 65535) return fail(YMX_EUNSUPPORTED, "yolo_loss: batch above 65535");
+    if (conv_ld != 0 && conv_ld < 3 * (5 + C)) return fail(YMX_EARG, "yolo_loss: cell stride %d below 3*(5+C) = %d", conv_ld, 3 * (5 + C));
+    const size_t need = yolo_loss_workspace_bytes(B, S);
+    if (!workspace || ws_bytes < need) return fail(YMX_EWORKSPACE, "yolo_loss: workspace %zu < %zu bytes", ws_bytes, need);
+    if (((uintptr_t)workspace) & 3) return fail(YMX_EARG, "yolo_loss: workspace must be 4-byte aligned");
+    return launch_yolo_loss(conv, conv_ld, pred, label, bboxes, B, S, C, n_boxes, stride, xyscale, anchors, iou_loss_threshold,
+                            out, per_image, workspace, (hipStream_t)stream);
+}
+
 int ymx_affine_act(const void *x, const float *scale, const float *shift, void *y, long long n_pix, int C, int act,
                    int dtype, void *stream) {
     if (!x || !y) return fail(YMX_EARG, "affine_act: null pointer");

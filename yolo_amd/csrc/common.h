@@ -220,6 +220,11 @@ int launch_affine_act(const void *x, const float *scale, const float *shift, voi
                       int dtype, hipStream_t s);
 int launch_bbox_iou(const float *b1, const float *b2, float *out, long long n, int giou,
                     hipStream_t s);
+int launch_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dtype, hipStream_t s);
+size_t yolo_loss_workspace_bytes(int B, int S);
+int launch_yolo_loss(const float *conv, int conv_ld, const float *pred, const float *label, const float *bboxes, int B, int S,
+                     int C, int NB, float stride, float xyscale, const float *anchors, float iou_thr, float *out,
+                     float *per_image, void *workspace, hipStream_t s);
 
 // A decode workgroup (256 threads) owns a segment of DEC_SEG consecutive candidates of one
 // scale of one image, walked in DEC_SS sub-steps of 64.

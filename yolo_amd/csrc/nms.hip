@@ -160,7 +160,7 @@ __device__ __forceinline__ float4 load_chunk(const float *__restrict__ col, int 
     return i0 < M ? *(const float4 *)(col + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-__global__ void __launch_bounds__(256, 6)
+__global__ void __launch_bounds__(256)      // ~108 registers: four workgroups per CU; capping them for more spills into the streaming loops
 nms_class_kernel(const NmsArgs a) {
     __shared__ __attribute__((aligned(16))) u64 buf[NMS_BUF + 8];
     __shared__ int hist[NMS_BINS];

@@ -1,0 +1,284 @@
+// Two kernels of the rows beyond plain detector inference:
+//   - SPP block of CSPDarknet53 (three stride-1 SAME max-pools of 13, 9 and 5 fused with the
+//     channel concat that follows them, /root/reference/backbones.py:254-259);
+//   - the YOLO loss of one scale, forward (/root/reference/losses.py:10-46 with the decode of
+//     utils.py:107-131 fused in), without materialising the [B,S,S,3,128] IoU tensor.
+#include "common.h"
+
+namespace ymx {
+
+// ---- SPP: y = concat(maxpool13(x), maxpool9(x), maxpool5(x), x) on the channel axis -------
+// max over a (2r+1)^2 window = max over rows of max over columns, and a 9-window is a 5-window
+// of 5-windows (13 likewise), so all three pools are three rounds of one horizontal and one
+// vertical 5-max over an LDS copy of the map.  A workgroup holds the whole H x W map of one
+// image for CH 16-byte channel chunks; threads map chunk-fastest, so the CH chunks of a pixel
+// are stored as one contiguous run.  Pixels outside the map do not take part (TensorFlow pads
+// SAME max-pools with -inf).
+template <typename T>
+__device__ __forceinline__ uint4 max16(const uint4 a, const uint4 b) {
+    uint4 o;
+    if constexpr (sizeof(T) == 4) {
+        o.x = __float_as_uint(fmaxf(__uint_as_float(a.x), __uint_as_float(b.x)));
+        o.y = __float_as_uint(fmaxf(__uint_as_float(a.y), __uint_as_float(b.y)));
+        o.z = __float_as_uint(fmaxf(__uint_as_float(a.z), __uint_as_float(b.z)));
+        o.w = __float_as_uint(fmaxf(__uint_as_float(a.w), __uint_as_float(b.w)));
+    } else {
+        auto m2 = [](uint32_t p, uint32_t r) {
+            const float lo = fmaxf(__uint_as_float(p << 16), __uint_as_float(r << 16));
+            const float hi = fmaxf(__uint_as_float(p & 0xffff0000u), __uint_as_float(r & 0xffff0000u));
+            return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+        };
+        o.x = m2(a.x, b.x); o.y = m2(a.y, b.y); o.z = m2(a.z, b.z); o.w = m2(a.w, b.w);
+    }
+    return o;
+}
+
+template <typename T, int CH>
+__global__ void __launch_bounds__(256)
+spp_concat_kernel(const T *__restrict__ x, T *__restrict__ y, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int KCH = 16 / (int)sizeof(T);
+    const int npix = H * W;
+    uint4 *bufA = (uint4 *)smem_raw;                 // [npix][CH]
+    uint4 *bufB = bufA + (size_t)npix * CH;          // [npix][CH]
+    const int t = threadIdx.x;
+    const int ch = t % CH, p0 = t / CH;
+    constexpr int PSTEP = 256 / CH;
+    const int b = blockIdx.y;
+    const int c0 = (blockIdx.x * CH + ch) * KCH;     // first channel of this thread's chunk
+    const bool chunk_ok = c0 < C;
+    const T *xb = x + (size_t)b * npix * C + c0;
+    T *yb = y + (size_t)b * npix * 4 * C + c0;
+
+    for (int p = p0; p < npix; p += PSTEP) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (chunk_ok) {
+            v = *(const uint4 *)(xb + (size_t)p * C);
+            *(uint4 *)(yb + (size_t)p * 4 * C + 3 * C) = v;
+        }
+        bufA[p * CH + ch] = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int round = 0; round < 3; ++round) {
+        for (int p = p0; p < npix; p += PSTEP) {        // horizontal 5-max: A -> B
+            const int r = p / W, c = p - r * W;
+            uint4 m = bufA[p * CH + ch];
+#pragma unroll
+            for (int d = -2; d <= 2; ++d)
+                if (d != 0 && (unsigned)(c + d) < (unsigned)W) m = max16<T>(m, bufA[(p + d) * CH + ch]);
+            bufB[p * CH + ch] = m;
+        }
+        __syncthreads();
+        for (int p = p0; p < npix; p += PSTEP) {        // vertical 5-max: B -> A, and out
+            const int r = p / W;
+            uint4 m = bufB[p * CH + ch];
+#pragma unroll
+            for (int d = -2; d <= 2; ++d)
+                if (d != 0 && (unsigned)(r + d) < (unsigned)H) m = max16<T>(m, bufB[(p + d * W) * CH + ch]);
+            bufA[p * CH + ch] = m;
+            if (chunk_ok) *(uint4 *)(yb + (size_t)p * 4 * C + (2 - round) * C) = m;   // 5 -> slot 2, 9 -> 1, 13 -> 0
+        }
+        __syncthreads();
+    }
+}
+
+int launch_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dtype, hipStream_t s) {
+    const int kch = dtype == YMX_BF16 ? 8 : 4;
+    const int nchunk = C / kch;
+    const size_t per_chunk = (size_t)H * W * 16 * 2;          // both LDS copies of one chunk
+    int ch = 8;
+    while (ch > 1 && (per_chunk * ch > 64 * 1024 || ch > nchunk)) ch >>= 1;
+    if (per_chunk * ch > 64 * 1024) return fail(YMX_EUNSUPPORTED, "spp_concat: map of %d x %d pixels too large (at most 2048 pixels)", H, W);
+    const size_t lds = per_chunk * ch;
+    dim3 grid((nchunk + ch - 1) / ch, B), block(256);
+#define YMX_SPP(T, CHV) hipLaunchKernelGGL((spp_concat_kernel<T, CHV>), grid, block, lds, s, (const T *)x, (T *)y, H, W, C)
+    if (dtype == YMX_BF16) {
+        if (ch == 8) YMX_SPP(bf16_t, 8); else if (ch == 4) YMX_SPP(bf16_t, 4); else if (ch == 2) YMX_SPP(bf16_t, 2); else YMX_SPP(bf16_t, 1);
+    } else {
+        if (ch == 8) YMX_SPP(float, 8); else if (ch == 4) YMX_SPP(float, 4); else if (ch == 2) YMX_SPP(float, 2); else YMX_SPP(float, 1);
+    }
+#undef YMX_SPP
+    return check_launch("spp_concat");
+}
+
+// ---- YOLO loss of one scale, forward ---------------------------------------------------------
+// centre-format IoU and GIoU exactly as /root/reference/utils.py:33-105 (divide_no_nan: 0 when
+// the divisor is 0)
+__device__ __forceinline__ float iou_cxcywh(float ax, float ay, float aw, float ah, float bx, float by, float bw, float bh,
+                                            float *giou) {
+    const float area1 = aw * ah, area2 = bw * bh;
+    const float ax0 = ax - aw * 0.5f, ay0 = ay - ah * 0.5f, ax1 = ax + aw * 0.5f, ay1 = ay + ah * 0.5f;
+    const float bx0 = bx - bw * 0.5f, by0 = by - bh * 0.5f, bx1 = bx + bw * 0.5f, by1 = by + bh * 0.5f;
+    const float iw = fmaxf(fminf(ax1, bx1) - fmaxf(ax0, bx0), 0.0f);
+    const float ih = fmaxf(fminf(ay1, by1) - fmaxf(ay0, by0), 0.0f);
+    const float inter = iw * ih;
+    const float uni = area1 + area2 - inter;
+    const float iou = uni != 0.0f ? inter / uni : 0.0f;
+    if (giou) {
+        const float ew = fmaxf(ax1, bx1) - fminf(ax0, bx0), eh = fmaxf(ay1, by1) - fminf(ay0, by0);
+        const float earea = ew * eh;
+        *giou = iou - (earea != 0.0f ? (earea - uni) / earea : 0.0f);
+    }
+    return iou;
+}
+
+// tf.nn.sigmoid_cross_entropy_with_logits: max(x, 0) - x z + log(1 + exp(-|x|))
+__device__ __forceinline__ float sce_logits(float z, float x) {
+    return fmaxf(x, 0.0f) - x * z + log1pf(expf(-fabsf(x)));
+}
+
+// One workgroup per 64 candidates (row, col, anchor order) of one image.  The candidates'
+// rows of `conv` and `label` are staged in LDS; lane = candidate in all four waves; wave q
+// sums the class cross-entropies of class slice q and takes the max IoU over ground-truth
+// boxes [q*NB/4, (q+1)*NB/4); wave 0 then forms the three loss terms and reduces them over
+// its 64 lanes into one partial per workgroup (summed per image, in order, by the second
+// kernel: no float atomics, the result is reproducible).
+struct LossArgs {
+    const float *conv, *pred, *label, *bboxes;
+    float *partial;              // [B][nseg][3]
+    int B, S, C, NB, nseg;
+    int conv_ld;                 // elements from one grid cell to the next in conv (>= 3*(5+C))
+    float stride, xyscale, anchor[3][2];
+    float input_size, iou_thr;
+};
+
+__global__ void __launch_bounds__(256)
+yolo_loss_kernel(const LossArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int D = 5 + a.C;
+    const int stage_words = 64 * D + 22 * (a.conv_ld - 3 * D);
+    float *sconv = (float *)smem_raw;                // span of conv rows, padding included
+    float *slabel = sconv + stage_words;             // [64][D]
+    float *sbox = slabel + 64 * D;                   // [NB][4]
+    float *sred = sbox + 4 * a.NB;                   // [2][4][64]: class sums, max IoU
+    const int t = threadIdx.x, lane = t & 63;
+    const int q = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int seg = blockIdx.x, b = blockIdx.y;
+    const int Ns = 3 * a.S * a.S;
+    const int c0 = seg * 64;
+    int nvalid = Ns - c0;
+    nvalid = nvalid > 64 ? 64 : nvalid;
+    const int cell0 = c0 / 3, a0 = c0 - cell0 * 3;
+    const int cl = c0 + nvalid - 1, cellL = cl / 3;
+    const int span = (cellL - cell0) * a.conv_ld + (cl - cellL * 3 + 1) * D - a0 * D;
+    const float *csrc = a.conv + ((size_t)b * a.S * a.S + cell0) * a.conv_ld + a0 * D;
+    const float *lsrc = a.label + ((size_t)b * Ns + c0) * D;
+    for (int i = t; i < span; i += 256) sconv[i] = csrc[i];
+    for (int i = t; i < nvalid * D; i += 256) slabel[i] = lsrc[i];
+    for (int i = t; i < 4 * a.NB; i += 256) sbox[i] = a.bboxes[(size_t)b * a.NB * 4 + i];
+    __syncthreads();
+
+    const bool live = lane < nvalid;
+    const int cme = c0 + lane, cellm = cme / 3, an = cme - cellm * 3;
+    const float *row = sconv + (cellm - cell0) * a.conv_ld + an * D - a0 * D;
+    const float *lab = slabel + lane * D;
+    float px = 0.f, py = 0.f, pw = 0.f, ph = 0.f, pconf = 0.f;
+    float csum = 0.f, miou = 0.f;
+    if (live) {
+        if (a.pred) {
+            const float *pr = a.pred + ((size_t)b * Ns + cme) * D;
+            px = pr[0]; py = pr[1]; pw = pr[2]; ph = pr[3]; pconf = pr[4];
+        } else {
+            const int col = cellm % a.S, rw = cellm / a.S;
+            const float half = 0.5f * (a.xyscale - 1.0f);
+            px = ((1.0f / (1.0f + expf(-row[0]))) * a.xyscale - half + (float)col) * a.stride;
+            py = ((1.0f / (1.0f + expf(-row[1]))) * a.xyscale - half + (float)rw) * a.stride;
+            pw = expf(row[2]) * a.anchor[an][0];
+            ph = expf(row[3]) * a.anchor[an][1];
+            pconf = 1.0f / (1.0f + expf(-row[4]));
+        }
+        const int cper = (a.C + 3) / 4;
+        for (int c = q * cper; c < (q + 1) * cper && c < a.C; ++c) csum += sce_logits(lab[5 + c], row[5 + c]);
+        const int bper = (a.NB + 3) / 4;
+        for (int j = q * bper; j < (q + 1) * bper && j < a.NB; ++j) {
+            const float v = iou_cxcywh(px, py, pw, ph, sbox[4 * j], sbox[4 * j + 1], sbox[4 * j + 2], sbox[4 * j + 3], nullptr);
+            miou = (j == q * bper) ? v : fmaxf(miou, v);
+        }
+        if (q * bper >= a.NB) miou = -INFINITY;         // this wave had no box: neutral in the max
+    }
+    sred[q * 64 + lane] = csum;
+    sred[256 + q * 64 + lane] = miou;
+    __syncthreads();
+    if (q == 0) {
+        float lg = 0.f, lc = 0.f, lp = 0.f;
+        if (live) {
+            const float prob_sum = (sred[lane] + sred[64 + lane]) + (sred[128 + lane] + sred[192 + lane]);
+            const float max_iou = fmaxf(fmaxf(sred[256 + lane], sred[320 + lane]), fmaxf(sred[384 + lane], sred[448 + lane]));
+            const float respond = lab[4];
+            float giou;
+            iou_cxcywh(px, py, pw, ph, lab[0], lab[1], lab[2], lab[3], &giou);
+            const float scale = 2.0f - 1.0f * lab[2] * lab[3] / (a.input_size * a.input_size);
+            lg = respond * scale * (1.0f - giou);
+            const float bgd = (1.0f - respond) * (max_iou < a.iou_thr ? 1.0f : 0.0f);
+            const float d = respond - pconf;
+            const float bce = sce_logits(respond, row[4]);
+            lc = (d * d) * (respond * bce + bgd * bce);
+            lp = respond * prob_sum;
+        }
+#pragma unroll
+        for (int dl = 32; dl > 0; dl >>= 1) {
+            lg += __shfl_xor(lg, dl);
+            lc += __shfl_xor(lc, dl);
+            lp += __shfl_xor(lp, dl);
+        }
+        if (lane == 0) {
+            float *o = a.partial + ((size_t)b * a.nseg + seg) * 3;
+            o[0] = lg; o[1] = lc; o[2] = lp;
+        }
+    }
+}
+
+// Sums the workgroup partials of every image in segment order, then averages over the
+// batch in image order: per_image [B][3] (may be null) and out [3] = (giou, conf, prob).
+__global__ void __launch_bounds__(256)
+yolo_loss_reduce_kernel(const float *__restrict__ partial, float *__restrict__ per_image, float *__restrict__ out,
+                        float *__restrict__ scratch, int B, int nseg) {
+    const int t = threadIdx.x;
+    for (int b = t; b < B; b += 256) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        const float *p = partial + (size_t)b * nseg * 3;
+        for (int i = 0; i < nseg; ++i) { s0 += p[3 * i]; s1 += p[3 * i + 1]; s2 += p[3 * i + 2]; }
+        scratch[3 * b] = s0; scratch[3 * b + 1] = s1; scratch[3 * b + 2] = s2;
+        if (per_image) { per_image[3 * b] = s0; per_image[3 * b + 1] = s1; per_image[3 * b + 2] = s2; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (t < 3) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += scratch[3 * b + t];
+        out[t] = s / (float)B;
+    }
+}
+
+size_t yolo_loss_workspace_bytes(int B, int S) {
+    if (B <= 0 || S <= 0) return 0;
+    const size_t nseg = ((size_t)3 * S * S + 63) / 64;
+    return ((size_t)B * nseg * 3 + (size_t)B * 3) * 4;
+}
+
+int launch_yolo_loss(const float *conv, int conv_ld, const float *pred, const float *label, const float *bboxes, int B, int S,
+                     int C, int NB, float stride, float xyscale, const float *anchors, float iou_thr, float *out,
+                     float *per_image, void *workspace, hipStream_t s) {
+    LossArgs a;
+    a.conv = conv; a.pred = pred; a.label = label; a.bboxes = bboxes;
+    a.partial = (float *)workspace;
+    a.B = B; a.S = S; a.C = C; a.NB = NB;
+    a.nseg = (3 * S * S + 63) / 64;
+    a.conv_ld = conv_ld > 0 ? conv_ld : 3 * (5 + C);
+    a.stride = stride; a.xyscale = xyscale;
+    for (int i = 0; i < 6; ++i) (&a.anchor[0][0])[i] = anchors[i];
+    a.input_size = (float)S * stride;
+    a.iou_thr = iou_thr;
+    const int D = 5 + C;
+    const size_t lds = ((size_t)64 * D + 22 * (size_t)(a.conv_ld - 3 * D) + (size_t)64 * D + 4 * (size_t)NB + 512) * 4;
+    if (lds > 64 * 1024) return fail(YMX_EUNSUPPORTED, "yolo_loss: %d classes / %d boxes / cell stride %d need %zu bytes of LDS", C, NB, a.conv_ld, lds);
+    hipLaunchKernelGGL(yolo_loss_kernel, dim3(a.nseg, B), dim3(256), lds, s, a);
+    int rc = check_launch("yolo_loss");
+    if (rc) return rc;
+    float *scratch = a.partial + (size_t)B * a.nseg * 3;
+    hipLaunchKernelGGL(yolo_loss_reduce_kernel, dim3(1), dim3(256), 0, s, a.partial, per_image, out, scratch, B, a.nseg);
+    return check_launch("yolo_loss_reduce");
+}
+
+}  // namespace ymx

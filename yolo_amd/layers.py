@@ -117,6 +117,16 @@ def upsample2x_concat(skip, x):
     return y
 
 
+def spp_concat(x):
+    """concat([maxpool13(x), maxpool9(x), maxpool5(x), x], -1), stride-1 SAME pools, in one
+    kernel (ymx_spp_concat; /root/reference/backbones.py:254-259)."""
+    x = _as_nhwc(x)
+    b, h, w, c = x.shape
+    y = _empty_like_nhwc(x, 4 * c)
+    _lib.launch("ymx_spp_concat", x, _lib.ptr(x), _lib.ptr(y), b, h, w, c, _lib.dtype_code(x.dtype))
+    return y
+
+
 class Upsample(nn.Module):
     """Bilinear x2, half-pixel centres, edge clamp (layers.py:33-39)."""
 

@@ -1,0 +1,98 @@
+"""YOLO loss (forward), same names and signatures as the reference's losses.py.
+
+Mirrors /root/reference/losses.py:10-70.  One fused HIP launch per scale (ymx_yolo_loss)
+reads the raw head map, the label tensor and the ground-truth boxes once and produces the
+three loss terms; the [B,S,S,3,128] IoU tensor of losses.py:27 is never materialised.
+Forward only: gradients are not provided.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .utils import _anchors_array
+
+N_BOXES = 128          # ground-truth slots per image in the target layout (losses.py:62)
+
+
+def _launch(conv5, conv_ld, pred5, label5, bboxes, stride, xyscale, anchors3x2, iou_loss_threshold, per_image=False):
+    B, S, C = conv5.shape[0], conv5.shape[1], conv5.shape[4] - 5
+    dev = conv5.device
+    out = torch.empty((3,), device=dev, dtype=torch.float32)
+    per = torch.empty((B, 3), device=dev, dtype=torch.float32) if per_image else None
+    L = _lib.lib()
+    ws_bytes = L.ymx_yolo_loss_workspace_bytes(B, S)
+    ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
+    anc = (ctypes.c_float * 6)(*[float(v) for v in np.asarray(anchors3x2, np.float32).reshape(-1)[:6]])
+    _lib.launch("ymx_yolo_loss", out, _lib.ptr(conv5), int(conv_ld), _lib.ptr(pred5), _lib.ptr(label5), _lib.ptr(bboxes),
+                B, S, C, int(bboxes.shape[1]), float(stride), float(xyscale), anc, float(iou_loss_threshold),
+                _lib.ptr(out), _lib.ptr(per), _lib.ptr(ws), ws_bytes)
+    return out, per
+
+
+def _check5(t, name):
+    _lib.require_gpu(t)
+    if t.dim() != 5 or t.shape[3] != 3 or t.shape[1] != t.shape[2]:
+        raise ValueError("%s: expected [B,S,S,3,5+C], got %s" % (name, tuple(t.shape)))
+    return t.float().contiguous()
+
+
+def yolo_loss(pred, conv, label, bboxes, input_size, iou_loss_threshold):
+    """(giou_loss, conf_loss, prob_loss), each a 0-dim float32 GPU tensor (losses.py:10-46).
+
+    pred [B,S,S,3,5+C] decoded (xywh, conf, ...), conv the raw map, label (xywh, respond,
+    class probabilities), bboxes [B,NB,4] centre-format ground truth.
+    """
+    conv5, pred5, label5 = _check5(conv, "conv"), _check5(pred, "pred"), _check5(label, "label")
+    if pred5.shape != conv5.shape or label5.shape != conv5.shape:
+        raise ValueError("pred, conv and label must have the same shape")
+    bx = bboxes.float().contiguous()
+    if bx.dim() != 3 or bx.shape[0] != conv5.shape[0] or bx.shape[2] != 4:
+        raise ValueError("bboxes: expected [B,NB,4], got %s" % (tuple(bx.shape),))
+    S = conv5.shape[1]
+    out, _ = _launch(conv5, 0, pred5, label5, bx, float(input_size) / S, 1.0, np.ones((3, 2), np.float32),
+                     iou_loss_threshold)
+    return out[0], out[1], out[2]
+
+
+def loss_at_scale(target, output, scale, num_classes, strides, iou_loss_threshold, xyscale, anchors, terms=False):
+    """Body of one closure of get_yolo_loss_at_scales (losses.py:52-66) for ``scale``:
+    target [B, S*S*3*(5+C) + 128*4], output [B,S,S,3*(5+C)] -> giou + conf + prob (0-dim
+    tensor); with terms=True the three terms as a [3] tensor.  The decode of ``output``
+    (decode_train) happens inside the kernel."""
+    _lib.require_gpu(target, output)
+    if output.dim() != 4 or output.shape[1] != output.shape[2] or output.shape[3] != 3 * (5 + num_classes):
+        raise ValueError("output: expected [B,S,S,3*(5+C)], got %s" % (tuple(output.shape),))
+    B, S = output.shape[0], output.shape[1]
+    D = 5 + num_classes
+    split = S * S * 3 * D
+    if target.dim() != 2 or target.shape[0] != B or target.shape[1] != split + N_BOXES * 4:
+        raise ValueError("target: expected [B, %d], got %s" % (split + N_BOXES * 4, tuple(target.shape)))
+    out5 = output.float().contiguous().view(B, S, S, 3, D)
+    tgt = target.float().contiguous()
+    labels = tgt[:, :split].contiguous().view(B, S, S, 3, D)
+    bboxes = tgt[:, split:].contiguous().view(B, N_BOXES, 4)
+    anc = _anchors_array(anchors)[scale]
+    out, _ = _launch(out5, 0, None, labels, bboxes, strides[scale], xyscale[scale], anc, iou_loss_threshold)
+    return out if terms else out.sum()
+
+
+def get_yolo_loss_at_scales(scales, num_classes, strides, iou_loss_threshold, xyscale, anchors, late_binding=False):
+    """List of loss(target, output) callables, one per scale, in the order of scales[::-1]
+    (losses.py:48-70).
+
+    In the reference every closure reads the loop variable ``scale`` when it is first traced,
+    after the loop has ended, so all of them use scales[0]; late_binding=True reproduces
+    that, the default gives each closure the scale of its own iteration (what the code
+    evidently intends)."""
+    order = list(scales)[::-1]
+    losses = []
+    for sc in order:
+        use = list(scales)[0] if late_binding else sc
+
+        def loss(target, output, _scale=use):
+            return loss_at_scale(target, output, _scale, num_classes, strides, iou_loss_threshold, xyscale, anchors)
+
+        losses.append(loss)
+    return losses
