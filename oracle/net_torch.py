@@ -287,3 +287,120 @@ def round_params_bf16(params):
         q["kernel"] = bf16_round(p["kernel"])
         out.append(q)
     return out
+
+
+# ---------------------------------------------------------------------------
+# CSPDarknet53 (backbones.py:62-264), REPAIRED.  The reference's class cannot be
+# constructed: it passes three positionals to ResidialBlock(filter_num1, filter_num2,
+# activation) (layers.py:93), and its second conv has 54 filters where every consumer
+# expects 64 (backbones.py:68).  The definition below is the evident intent:
+# ResidialBlock(in, f1, f2) -> ResidialBlock(f1, f2), 54 -> 64.  There is no oracle for it
+# even in principle; this restatement is what the product is checked against.
+# Stack items: ("conv", k, cout, down) or ("res", f1, f2); stacks in attribute order.
+# ---------------------------------------------------------------------------
+
+def cspdarknet53_stacks():
+    def csp(n, f_in, f_mid, f_res1):
+        main = [("conv", 1, f_mid, False)] + [("res", f_res1, f_mid)] * n + [("conv", 1, f_mid, False)]
+        return main
+    return [
+        ("layer_stack_1", [("conv", 3, 32, False), ("conv", 3, 64, True)]),
+        ("layer_stack_2", [("conv", 1, 64, False)]),
+        ("layer_stack_2_skip", csp(1, 64, 64, 32)),
+        ("layer_stack_3", [("conv", 1, 64, False), ("conv", 3, 128, True)]),
+        ("layer_stack_4", csp(2, 128, 64, 64)),
+        ("layer_stack_4_skip", [("conv", 1, 64, False)]),
+        ("layer_stack_5", [("conv", 1, 128, False), ("conv", 3, 256, True)]),
+        ("layer_stack_6", csp(8, 256, 128, 128)),
+        ("layer_stack_6_skip", [("conv", 1, 128, False)]),
+        ("layer_stack_7", [("conv", 1, 256, False)]),
+        ("layer_stack_8", [("conv", 3, 512, True)]),
+        ("layer_stack_9", csp(8, 512, 256, 256)),
+        ("layer_stack_9_skip", [("conv", 1, 256, False)]),
+        ("layer_stack_10", [("conv", 1, 512, False)]),
+        ("layer_stack_11", [("conv", 3, 1024, True)]),
+        ("layer_stack_12", csp(4, 1024, 512, 512)),
+        ("layer_stack_12_skip", [("conv", 1, 512, False)]),
+        ("layer_stack_13", [("conv", 1, 1024, False), ("conv", 1, 512, False), ("conv", 3, 1024, False), ("conv", 1, 512, False)]),
+        ("layer_stack_14", [("conv", 1, 512, False), ("conv", 3, 1024, False), ("conv", 1, 512, False)]),
+    ]
+
+
+# input channels of every stack (the data flow of CSPDarknet53.call, backbones.py:175-264)
+_CSP_INPUT = {"layer_stack_1": 3, "layer_stack_2": 64, "layer_stack_2_skip": 64, "layer_stack_3": 128,
+              "layer_stack_4": 128, "layer_stack_4_skip": 128, "layer_stack_5": 128, "layer_stack_6": 256,
+              "layer_stack_6_skip": 256, "layer_stack_7": 256, "layer_stack_8": 256, "layer_stack_9": 512,
+              "layer_stack_9_skip": 512, "layer_stack_10": 512, "layer_stack_11": 512, "layer_stack_12": 1024,
+              "layer_stack_12_skip": 1024, "layer_stack_13": 1024, "layer_stack_14": 2048}
+
+
+def cspdarknet53_specs():
+    """Flat conv specs (k, cin, cout, down, act) in attribute order, residual blocks expanded
+    (1x1 then 3x3), the order of the product's parameters."""
+    specs = []
+    for name, items in cspdarknet53_stacks():
+        cin = _CSP_INPUT[name]
+        for it in items:
+            if it[0] == "conv":
+                specs.append((it[1], cin, it[2], it[3], "mish"))
+                cin = it[2]
+            else:
+                specs.append((1, cin, it[1], False, "mish"))
+                specs.append((3, it[1], it[2], False, "mish"))
+                cin = it[2]
+    return specs
+
+
+def cspdarknet53_forward(params, x, round_fn=None):
+    """x [B,S,S,3] -> (route_1 [B,S/8,S/8,256], route_2 [B,S/16,S/16,512], x [B,S/32,S/32,512]);
+    backbones.py:175-264 on the repaired definition.  SPP: stride-1 SAME max-pools of 13, 9,
+    5 concatenated with their input (backbones.py:254-259; padding never wins a max)."""
+    rf = round_fn if round_fn is not None else (lambda t: t)
+    it = iter(params)
+    stacks = dict(cspdarknet53_stacks())
+
+    def run(name, t):
+        for item in stacks[name]:
+            if item[0] == "conv":
+                t = rf(yolo_conv(t, next(it), item[3], "mish"))
+            else:
+                y = rf(yolo_conv(t, next(it), False, "mish"))
+                y = yolo_conv(y, next(it), False, "mish")
+                t = rf(t + y)
+        return t
+
+    # parameters are consumed in attribute order, so run the stacks in that order and keep
+    # the results the data flow needs
+    x = run("layer_stack_1", x)
+    route = run("layer_stack_2", x)
+    x = run("layer_stack_2_skip", x)
+    x = torch.cat([x, route], dim=-1)
+    x = run("layer_stack_3", x)
+    route = x
+    x = run("layer_stack_4", x)
+    route = run("layer_stack_4_skip", route)
+    x = torch.cat([x, route], dim=-1)
+    x = run("layer_stack_5", x)
+    route = x
+    x = run("layer_stack_6", x)
+    route = run("layer_stack_6_skip", route)
+    x = torch.cat([x, route], dim=-1)
+    x = run("layer_stack_7", x)
+    route_1 = x
+    x = run("layer_stack_8", x)
+    route = x
+    x = run("layer_stack_9", x)
+    route = run("layer_stack_9_skip", route)
+    x = torch.cat([x, route], dim=-1)
+    x = run("layer_stack_10", x)
+    route_2 = x
+    x = run("layer_stack_11", x)
+    route = x
+    x = run("layer_stack_12", x)
+    route = run("layer_stack_12_skip", route)
+    x = torch.cat([x, route], dim=-1)
+    x = run("layer_stack_13", x)
+    xn = x.permute(0, 3, 1, 2)
+    x = torch.cat([F.max_pool2d(xn, k, 1, k // 2) for k in (13, 9, 5)] + [xn], dim=1).permute(0, 2, 3, 1).contiguous()
+    x = run("layer_stack_14", x)
+    return route_1, route_2, x

@@ -70,3 +70,66 @@ def test_spp_concat_exact(shape, dtype):
     got = spp_concat(x.to(DEV))
     assert got.shape == (B, H, W, 4 * C) and got.dtype == dtype
     assert torch.equal(got.float().cpu(), want)
+
+
+def test_cspdarknet53_fp32_vs_oracle():
+    """The repaired CSPDarknet53 (module API, zero-copy concats, fused SPP) against the torch-CPU
+    restatement of the same repaired definition, fp32, 64x64 and 96x96 inputs."""
+    from oracle import net_torch as N
+    from yolo_amd.backbones import CSPDarknet53
+    params = N.init_params(N.cspdarknet53_specs(), seed=3, init="variance")
+    net = CSPDarknet53()
+    net.load_reference_params(params)
+    net.to(DEV)
+    for side, batch in ((64, 2), (96, 1)):
+        x = torch.rand(batch, side, side, 3, generator=torch.Generator().manual_seed(side))
+        want = N.cspdarknet53_forward(params, x)
+        got = net(x.to(DEV))
+        assert [tuple(t.shape) for t in got] == [(batch, side // 8, side // 8, 256), (batch, side // 16, side // 16, 512),
+                                                 (batch, side // 32, side // 32, 512)]
+        for g, w in zip(got, want):
+            assert g.dtype == torch.float32
+            err = float((g.cpu() - w).abs().max() / w.abs().max())
+            assert err < 1e-3, err
+
+
+def test_cspdarknet53_bf16_vs_rounding_oracle():
+    from oracle import net_torch as N
+    from yolo_amd.backbones import CSPDarknet53
+    params = N.init_params(N.cspdarknet53_specs(), seed=4, init="variance")
+    net = CSPDarknet53(dtype=torch.bfloat16)
+    net.load_reference_params(params)
+    net.to(DEV)
+    x = torch.rand(2, 64, 64, 3, generator=torch.Generator().manual_seed(7))
+    want = N.cspdarknet53_forward(N.round_params_bf16(params), x, round_fn=N.bf16_round)
+    got = net(x.to(DEV))
+    for g, w in zip(got, want):
+        assert g.dtype == torch.bfloat16
+        rms = float((g.float().cpu() - w).pow(2).mean().sqrt() / w.pow(2).mean().sqrt())
+        assert rms < 2e-2, rms
+
+
+def test_conv_writes_into_a_channel_slice():
+    """YOLOConv(out=...): the output lands in a slice of a wider NHWC buffer, nothing else is touched."""
+    from oracle import net_torch as N
+    from yolo_amd.layers import YOLOConv, ResidialBlock
+    g = torch.Generator().manual_seed(11)
+    x = N.bf16_round(torch.randn(2, 9, 7, 16, generator=g))
+    p = {"kernel": N.bf16_round(torch.randn(1, 1, 16, 24, generator=g) * 0.2), "bias": torch.randn(24, generator=g)}
+    layer = YOLOConv((1, 1, 24), dtype=torch.bfloat16)
+    layer.load_reference_params(p)
+    layer.to(DEV)
+    want = layer(x.to(DEV).bfloat16())
+    cat = torch.full((2, 9, 7, 40), 3.0, device=DEV, dtype=torch.bfloat16)
+    got = layer(x.to(DEV).bfloat16(), out=cat[..., 8:32])
+    assert got.data_ptr() == cat[..., 8:32].data_ptr()
+    assert torch.equal(cat[..., 8:32], want) and bool((cat[..., :8] == 3).all()) and bool((cat[..., 32:] == 3).all())
+    with pytest.raises(ValueError):
+        layer(x.to(DEV).bfloat16(), out=cat[..., 8:30])
+    blk = ResidialBlock(8, 16, dtype=torch.bfloat16)
+    for c, cin in zip(blk.layer_stack, (16, 8)):
+        c.build(cin, generator=g)
+    blk.to(DEV)
+    want = blk(x.to(DEV).bfloat16())
+    blk(x.to(DEV).bfloat16(), out=cat[..., 0:16])
+    assert torch.equal(cat[..., 0:16], want)

@@ -100,6 +100,21 @@ def test_module_interface_matches_reference():
     assert got == want
 
 
+def test_cspdarknet53_structure():
+    """The repaired CSPDarknet53: attribute names of the reference (backbones.py:66-173), 78
+    convolutions whose shapes follow the data flow of backbones.py:175-264."""
+    from yolo_amd import backbones
+    from oracle import net_torch as N
+    m = backbones.CSPDarknet53(seed=0)
+    names = [n for n, _ in N.cspdarknet53_stacks()]
+    assert all(hasattr(m, n) for n in names) and len(names) == 19
+    got = [(c.kernel_size, c.in_channels, c.filters, c.downsample) for c in m.conv_layers()]
+    want = [(k, ci, co, d) for k, ci, co, d, _ in N.cspdarknet53_specs()]
+    assert got == want and len(got) == 78
+    assert [len(getattr(m, n)) for n in ("layer_stack_2_skip", "layer_stack_6", "layer_stack_12", "layer_stack_13")] == [3, 10, 6, 4]
+    assert m.layer_stack_1[1].filters == 64 and m.layer_stack_14[0].in_channels == 2048
+
+
 def test_no_cpu_fallback():
     from yolo_amd import layers, utils
     x = torch.zeros(1, 8, 8, 8)

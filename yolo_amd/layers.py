@@ -238,9 +238,11 @@ class YOLOConv(nn.Module):
         return (h + 1 - k) // 2 + 1, (w + 1 - k) // 2 + 1
 
     # -- forward ----------------------------------------------------------------
-    def forward(self, x, residual=None, out_dtype=None):
+    def forward(self, x, residual=None, out_dtype=None, out=None):
         """x NHWC -> NHWC.  residual (same shape as the output) is added after the
-        activation inside the kernel; out_dtype overrides the output element type."""
+        activation inside the kernel; out_dtype overrides the output element type; out, if
+        given, receives the result: a [B,H',W',Cout] view whose pixels may be spaced wider than
+        Cout (a channel slice of a larger NHWC buffer: how a concat is written in place)."""
         x = _as_nhwc(x)
         if self.in_channels is None:
             self.build(x.shape[-1])
@@ -257,7 +259,16 @@ class YOLOConv(nn.Module):
         wp, scale, shift, _ = self.packed(cdt)
         b, h, w, _c = x.shape
         oh, ow = self.output_hw(h, w)
-        y = _empty_like_nhwc(x, cout, oh, ow, dtype=odt)
+        y_ld = 0
+        if out is not None:
+            if self.act_fn is not None:
+                raise ValueError("YOLOConv: out= is not supported with a callable activation")
+            if (tuple(out.shape) != (b, oh, ow, cout) or out.dtype != odt or out.device != x.device or out.stride(3) != 1 or
+                    out.stride(1) != ow * out.stride(2) or out.stride(0) != oh * ow * out.stride(2)):
+                raise ValueError("YOLOConv: out must be a [%d,%d,%d,%d] %s view with dense pixels" % (b, oh, ow, cout, odt))
+            y, y_ld = out, out.stride(2)
+        else:
+            y = _empty_like_nhwc(x, cout, oh, ow, dtype=odt)
         fuse_res = residual is not None and self.act_fn is None
         if fuse_res:
             residual = _as_nhwc(residual)
@@ -268,7 +279,7 @@ class YOLOConv(nn.Module):
                 residual = residual.to(want)
         _lib.launch("ymx_conv2d_fused_ex", x, _lib.ptr(x), _lib.ptr(wp), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual) if fuse_res else None,
             _lib.ptr(y), b, h, w, cin, cout, k, 2 if self.downsample else 1, self.act_code, code,
-            _lib.dtype_code(x.dtype), _lib.dtype_code(odt), 0, 0, 0)
+            _lib.dtype_code(x.dtype), _lib.dtype_code(odt), 0, 0, y_ld)
         if self.act_fn is not None:
             y = self.act_fn(y)
             if residual is not None:
@@ -292,7 +303,7 @@ class ResidialBlock(nn.Module):
             YOLOConv(filters_shape=(3, 3, filter_num2), activation=activation, dtype=dtype),
         ])
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         short_cut = x
         x = self.layer_stack[0](x)
-        return self.layer_stack[1](x, residual=short_cut)
+        return self.layer_stack[1](x, residual=short_cut, out=out)
