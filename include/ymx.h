@@ -271,6 +271,22 @@ int ymx_yolo_loss(const float *conv, int conv_ld, const float *pred, const float
                   const float *anchors /* host */, float iou_loss_threshold, float *out,
                   float *per_image, void *workspace, size_t ws_bytes, void *stream);
 
+/* ---- label assignment ---------------------------------------------------------
+ * Replaces WIDERDataset.preprocess_true_boxes (dataset.py:387-482) for a batch: every
+ * ground-truth box (xmin, ymin, xmax, ymax, class; boxes [B,max_boxes,5] fp32, counts [B] or
+ * NULL = max_boxes each), in order, claims on each scale the anchors of its grid cell whose
+ * IoU with it (in grid units) exceeds 0.3, or failing that the single best anchor of all
+ * nine; a claimed label row becomes (cx, cy, w, h in pixels, 1, class probabilities smoothed
+ * by 0.01) and the box is appended to that scale's ring of 128 ground-truth boxes.
+ * labels: host array of 3 device pointers [B,S_i,S_i,3,5+C] fp32, S_i = input_size /
+ * strides[i]; gt_boxes: host array of 3 device pointers [B,128,4] fp32; both are zeroed by
+ * the call.  anchors_grid: host [3][3][2], anchor sizes in grid units (pixels / stride).
+ * Arithmetic in double, as the reference's numpy code.  Boxes whose class is outside
+ * [0, C) or whose cell falls outside the grid are skipped (the reference raises). */
+int ymx_assign_labels(const float *boxes, const int *counts, int B, int max_boxes, int input_size,
+                      int C, const float *strides /* host */, const float *anchors_grid /* host */,
+                      float *const *labels /* host */, float *const *gt_boxes /* host */, void *stream);
+
 /* ---- box IoU ----------------------------------------------------------------
  * Replaces bbox_iou (utils.py:33-63) and, with giou != 0, bbox_giou
  * (utils.py:65-105) on n pairs of centre-format (cx,cy,w,h) fp32 boxes that the

@@ -133,3 +133,45 @@ def test_conv_writes_into_a_channel_slice():
     want = blk(x.to(DEV).bfloat16())
     blk(x.to(DEV).bfloat16(), out=cat[..., 0:16])
     assert torch.equal(cat[..., 0:16], want)
+
+
+def _random_boxes(rng, n, size, C):
+    wh = np.exp(rng.normal(3.5, 1.0, (n, 2))).clip(4, size * 0.9)
+    ctr = rng.uniform(0, size, (n, 2))
+    x0y0 = np.clip(ctr - wh / 2, 0, size - 2)
+    x1y1 = np.clip(ctr + wh / 2, x0y0 + 1, size - 1)
+    cls = rng.integers(0, C, (n, 1))
+    return np.floor(np.concatenate([x0y0, x1y1, cls], 1))      # integer pixel corners, as a dataset holds them
+
+
+@pytest.mark.parametrize("C,size,literal", [(1, 416, False), (80, 416, False), (3, 608, False), (1, 416, True)])
+def test_assign_labels_vs_oracle(C, size, literal):
+    from oracle import labels_np as LB
+    from yolo_amd import dataset as DS
+    import yolo_amd as Y
+    rng = np.random.default_rng(C + size)
+    B, nmax = 5, 40
+    counts = np.array([40, 0, 1, 17, 33], np.int32)
+    boxes = np.zeros((B, nmax, 5), np.float32)
+    for b in range(B):
+        boxes[b, :counts[b]] = _random_boxes(rng, counts[b], size, C)
+    boxes[0, 5] = boxes[0, 4]                                  # an exact duplicate: the later one overwrites
+    cfg = Y.config
+    ag = DS.scale_anchors(literal=literal)
+    np.testing.assert_array_equal(ag, LB.scale_anchors(cfg["anchors"], cfg["strides"], literal).astype(np.float32))
+    got = DS.preprocess_true_boxes(torch.from_numpy(boxes).to(DEV), torch.from_numpy(counts).to(DEV), size, C,
+                                   anchors_grid=ag)
+    for b in range(B):
+        want = LB.preprocess_true_boxes(boxes[b, :counts[b]], size, C, cfg["strides"], ag.astype(np.float64))
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g[b].cpu().numpy(), w.astype(np.float32))
+    assert float(got[0][0].sum()) > 0 and float(got[0][1].abs().sum()) == 0
+    tg = DS.pack_targets(*got)
+    assert [tuple(t.shape) for t in tg] == [(B, (size // s) ** 2 * 3 * (5 + C) + 512) for s in cfg["strides"]]
+    # the targets feed the loss as they are
+    from yolo_amd import losses as L
+    S = size // 32
+    out = torch.randn(B, S, S, 3 * (5 + C), generator=torch.Generator().manual_seed(1)).to(DEV)
+    val = L.loss_at_scale(tg[2], out, 2, C, cfg["strides"], 0.5, cfg["xyscale"], cfg["anchors"], terms=True)
+    want = LN.loss_at_scale(tg[2].cpu().numpy(), out.cpu().numpy(), 2, C, P.STRIDES, 0.5, P.XYSCALE, P.ANCHORS)[1]
+    np.testing.assert_allclose(val.cpu().numpy().astype(np.float64), np.array(want, np.float64), rtol=1e-3)

@@ -371,3 +371,39 @@ def test_loss_known_answers():
     out = conv.reshape(1, 1, 1, -1)
     assert fs[0](target, out) == fs[1](target, out) == fs[2](target, out) == fs2[2](target, out)
     assert fs2[0](target, out) != fs2[2](target, out)
+
+
+def test_label_assignment_known_answers():
+    """Hand-derived: a 64x64 box centred at (100, 60) in a 416 image.  Grid cells: stride 8 ->
+    (12, 7), 16 -> (6, 3), 32 -> (3, 1).  In grid units the box is 8x8 / 4x4 / 2x2; against the
+    stride-16 anchors (36,75)/16, (76,55)/16, (72,146)/16 = 2.25x4.69, 4.75x3.44, 4.5x9.1 the
+    IoUs are inter/union with the anchor centred on the cell centre."""
+    from oracle import labels_np as LB
+    ag = LB.scale_anchors(P.ANCHORS.reshape(-1), P.STRIDES)
+    box = np.array([[68, 28, 132, 92, 0]], np.float64)
+    ls, lm, ll, bs, bm, bl = LB.preprocess_true_boxes(box, 416, 2, P.STRIDES, ag)
+    assert ls.shape == (52, 52, 3, 7) and lm.shape == (26, 26, 3, 7) and ll.shape == (13, 13, 3, 7)
+    # stride 16: box (6.25, 3.75, 4, 4) vs anchor 1 (4.75 x 3.4375) centred (6.5, 3.5)
+    iw = min(6.25 + 2, 6.5 + 2.375) - max(6.25 - 2, 6.5 - 2.375)
+    ih = min(3.75 + 2, 3.5 + 1.71875) - max(3.75 - 2, 3.5 - 1.71875)
+    iou = iw * ih / (16 + 4.75 * 3.4375 - iw * ih)
+    assert iou > 0.3
+    np.testing.assert_allclose(lm[3, 6, 1], [100, 60, 64, 64, 1, 0.995, 0.005])
+    np.testing.assert_allclose(bm[0], [100, 60, 64, 64])
+    assert lm[..., 4].sum() >= 1 and bm[1:].sum() == 0
+    # every responsible row carries the same box and smoothed one-hot
+    for lab in (ls, lm, ll):
+        rows = lab[lab[..., 4] == 1]
+        assert np.all(rows[:, :4] == [100, 60, 64, 64]) and np.allclose(rows[:, 5:], [0.995, 0.005])
+    # a tiny box matches no anchor above 0.3: exactly one row overall, at the best anchor
+    tiny = np.array([[200, 200, 203, 203, 1]], np.float64)
+    out = LB.preprocess_true_boxes(tiny, 416, 2, P.STRIDES, ag)
+    assert sum(int(l[..., 4].sum()) for l in out[:3]) == 1 and int(out[0][..., 4].sum()) == 1
+    assert out[0][25, 25, 0, 4] == 1                    # stride 8, cell (25, 25), the smallest anchor
+    # the literal reading of dataset.py:51,440: one number per scale
+    lit = LB.scale_anchors(P.ANCHORS.reshape(-1), P.STRIDES, literal=True)
+    assert lit[0].tolist() == [[12, 12]] * 3 and lit[2].tolist() == [[19, 19]] * 3
+    # letterbox bookkeeping (utils.py:19-31): 200 x 400 (h x w) into 416: scale 1.04, pad_y 104, pad_x 0
+    bx, scale, px, py = LB.letterbox_boxes(np.array([[10., 20., 110., 120., 0.]]), 200, 400, 416)
+    assert abs(scale - 1.04) < 1e-12 and (px, py) == (0, 104)
+    np.testing.assert_allclose(bx[0, :4], [10.4, 124.8, 114.4, 228.8])

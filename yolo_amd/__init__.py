@@ -13,6 +13,7 @@ from . import layers
 from . import backbones
 from . import detectors
 from . import losses
+from . import dataset
 from . import engine
 from . import dist
 from .engine import Detector

@@ -1,8 +1,11 @@
-// Two kernels of the rows beyond plain detector inference:
+// Kernels of the rows beyond plain detector inference:
 //   - SPP block of CSPDarknet53 (three stride-1 SAME max-pools of 13, 9 and 5 fused with the
 //     channel concat that follows them, /root/reference/backbones.py:254-259);
 //   - the YOLO loss of one scale, forward (/root/reference/losses.py:10-46 with the decode of
-//     utils.py:107-131 fused in), without materialising the [B,S,S,3,128] IoU tensor.
+//     utils.py:107-131 fused in), without materialising the [B,S,S,3,128] IoU tensor;
+//   - label assignment for a batch (/root/reference/dataset.py:387-482).
+#include <cstring>
+
 #include "common.h"
 
 namespace ymx {
@@ -281,4 +284,109 @@ int launch_yolo_loss(const float *conv, int conv_ld, const float *pred, const fl
     return check_launch("yolo_loss_reduce");
 }
 
+
+// ---- label assignment ------------------------------------------------------------------------
+// WIDERDataset.preprocess_true_boxes (/root/reference/dataset.py:387-482) for a whole batch, on
+// the device, so that the label tensors (3.6 MB per 416x416 image at 80 classes, nearly all
+// zeros) are born in HBM instead of crossing PCIe.  Boxes of one image are applied in order
+// (a later box overwrites a cell an earlier one claimed), so one wavefront walks an image's
+// boxes serially; its lanes split the 5+C values of each label row.  Arithmetic in double,
+// as the reference's numpy code; the stored values are rounded to fp32 once.
+struct LabelArgs {
+    const float *boxes;          // [B][nmax][5]: xmin, ymin, xmax, ymax, class
+    const int *counts;           // [B]
+    float *label[3];             // [B][S_i][S_i][3][5+C], zeroed by the caller of the kernel
+    float *gt[3];                // [B][128][4], zeroed likewise
+    int B, nmax, C, S[3];
+    double stride[3], anchor[3][3][2];       // anchors in grid units
+};
+
+__global__ void __launch_bounds__(64)
+assign_labels_kernel(const LabelArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int D = 5 + a.C;
+    int n = a.counts ? a.counts[b] : a.nmax;
+    n = n > a.nmax ? a.nmax : n;
+    int cnt[3] = {0, 0, 0};
+    for (int k = 0; k < n; ++k) {
+        const float *bx = a.boxes + ((size_t)b * a.nmax + k) * 5;
+        const double x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
+        const int cls = (int)bx[4];
+        if (cls < 0 || cls >= a.C) continue;
+        const double xywh[4] = {(x1 + x0) * 0.5, (y1 + y0) * 0.5, x1 - x0, y1 - y0};
+        const double lo = 0.01 * (1.0 / a.C), hi = 1.0 * (1 - 0.01) + lo;
+        double iou[3][3];
+        int gx[3], gy[3];
+        bool any_pos = false;
+        auto write = [&](int i, int an) {
+            if ((unsigned)gx[i] >= (unsigned)a.S[i] || (unsigned)gy[i] >= (unsigned)a.S[i]) return;
+            float *row = a.label[i] + ((((size_t)b * a.S[i] + gy[i]) * a.S[i] + gx[i]) * 3 + an) * D;
+            for (int c = lane; c < D; c += 64)
+                row[c] = (float)(c < 4 ? xywh[c] : (c == 4 ? 1.0 : (c - 5 == cls ? hi : lo)));
+        };
+        auto push = [&](int i) {
+            const int ind = cnt[i] % 128;
+            if (lane < 4) a.gt[i][((size_t)b * 128 + ind) * 4 + lane] = (float)xywh[lane];
+            ++cnt[i];
+        };
+        for (int i = 0; i < 3; ++i) {
+            const double sx = 1.0 * xywh[0] / a.stride[i], sy = 1.0 * xywh[1] / a.stride[i];
+            const double sw = 1.0 * xywh[2] / a.stride[i], sh = 1.0 * xywh[3] / a.stride[i];
+            gx[i] = (int)floor(sx);
+            gy[i] = (int)floor(sy);
+            const double cx = gx[i] + 0.5, cy = gy[i] + 0.5;
+            bool pos = false;
+            for (int an = 0; an < 3; ++an) {
+                const double aw = a.anchor[i][an][0], ah = a.anchor[i][an][1];
+                const double a1 = sw * sh, a2 = aw * ah;
+                const double lx = fmax(sx - sw * 0.5, cx - aw * 0.5), ly = fmax(sy - sh * 0.5, cy - ah * 0.5);
+                const double rx = fmin(sx + sw * 0.5, cx + aw * 0.5), ry = fmin(sy + sh * 0.5, cy + ah * 0.5);
+                const double inter = fmax(rx - lx, 0.0) * fmax(ry - ly, 0.0);
+                const double uni = a1 + a2 - inter;
+                iou[i][an] = uni != 0.0 ? inter / uni : 0.0;
+                if (iou[i][an] > 0.3) { write(i, an); pos = true; }
+            }
+            if (pos) { push(i); any_pos = true; }
+        }
+        if (!any_pos) {
+            int best = 0;
+            for (int j = 1; j < 9; ++j)
+                if (iou[j / 3][j % 3] > iou[best / 3][best % 3]) best = j;
+            write(best / 3, best % 3);
+            push(best / 3);
+        }
+    }
+}
+
+int launch_assign_labels(const LabelArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(assign_labels_kernel, dim3(a.B), dim3(64), 0, s, a);
+    return check_launch("assign_labels");
+}
+
 }  // namespace ymx
+
+extern "C" int ymx_assign_labels(const float *boxes, const int *counts, int B, int max_boxes, int input_size, int C,
+                                 const float *strides, const float *anchors_grid, float *const *labels, float *const *gt_boxes,
+                                 void *stream) {
+    using namespace ymx;
+    if (!boxes || !strides || !anchors_grid || !labels || !gt_boxes) return fail(YMX_EARG, "assign_labels: null pointer");
+    if (B <= 0 || max_boxes <= 0 || input_size <= 0 || C <= 0) return fail(YMX_EARG, "assign_labels: non-positive size");
+    LabelArgs a;
+    memset(&a, 0, sizeof(a));
+    a.boxes = boxes; a.counts = counts; a.B = B; a.nmax = max_boxes; a.C = C;
+    for (int i = 0; i < 3; ++i) {
+        if (!labels[i] || !gt_boxes[i]) return fail(YMX_EARG, "assign_labels: output %d missing", i);
+        if (!(strides[i] > 0.0f)) return fail(YMX_EARG, "assign_labels: stride %d not positive", i);
+        a.label[i] = labels[i]; a.gt[i] = gt_boxes[i];
+        a.stride[i] = strides[i];
+        a.S[i] = (int)(input_size / (int)strides[i]);
+        for (int j = 0; j < 6; ++j) (&a.anchor[i][0][0])[j] = anchors_grid[i * 6 + j];
+        const size_t lbytes = (size_t)B * a.S[i] * a.S[i] * 3 * (5 + C) * 4;
+        if (hipMemsetAsync(labels[i], 0, lbytes, (hipStream_t)stream) != hipSuccess ||
+            hipMemsetAsync(gt_boxes[i], 0, (size_t)B * 128 * 4 * 4, (hipStream_t)stream) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(YMX_ELAUNCH, "assign_labels: hipMemsetAsync failed");
+        }
+    }
+    return launch_assign_labels(a, (hipStream_t)stream);
+}
