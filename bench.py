@@ -51,6 +51,8 @@ def conv_kernel_name(op):
     bf16 = op.dtype == 1
     if fam in ("halo", "dma", "dma4"):
         return "conv_igemm_%s_bf16_256x256" % fam
+    if fam == "halo192":
+        return "conv_igemm_halo_bf16_256x192"
     if fam == "slab2":
         return "conv_igemm_slab2_bf16_cin%d" % op.Cin
     if fam == "dma2":
@@ -64,7 +66,8 @@ def conv_kernel_name(op):
 
 # bench label -> device kernel name in the rocprofv3 summaries under profiles/
 PMC_KERNEL = {
-    "conv_igemm_halo_bf16_256x256": "conv_igemm_halo_kernel<bf16>",
+    "conv_igemm_halo_bf16_256x256": "conv_igemm_halo_kernel<bf16, 4>",
+    "conv_igemm_halo_bf16_256x192": "conv_igemm_halo_kernel<bf16, 3>",
     "conv_igemm_dma_bf16_256x256": "conv_igemm_dma_kernel<bf16, 256>",
     "conv_igemm_dma4_bf16_256x256": "conv_igemm_dma4_kernel<bf16>",
 }

@@ -55,7 +55,9 @@ const char *ymx_last_error(void);
  * 4) of the 32- and 64-channel narrow-layer tiles.  "dma_narrow": bf16 layers of <= 128
  * output channels with at least dma_min_tiles 256-pixel tiles run on the LDS-DMA kernels
  * (2, the default: with the input-resident kernel for 3x3 stride 1 and 32 or 64 input
- * channels; 1: without it) or on the register-staged kernel (0).  All kernels add the K
+ * channels; 1: without it) or on the register-staged kernel (0).  "halo_pixels": pixels per
+ * tile of the resident-slab 3x3 kernel (0, the default: 192 where that shortens the launch,
+ * else 256; 192 or 256 force one).  All kernels add the K
  * terms in the same order: results do not depend on these options. */
 int ymx_set_option(const char *name, long long value);
 
@@ -130,7 +132,7 @@ typedef struct ymx_op {
 int ymx_run_program(const ymx_op *ops /* host */, int n_ops, void *stream);
 
 /* Diagnostic (no counterpart in the reference): the kernel family ymx_run_program would
- * launch for a convolution op with the calling thread's options -- "halo", "dma", "dma4",
+ * launch for a convolution op with the calling thread's options -- "halo", "halo192", "dma", "dma4",
  * "dma2", "slab2", "igemm", "first_rows" or "direct" (a static string) -- or NULL with
  * ymx_last_error() set when the op is invalid.  Nothing is launched.  Benchmarks use it to
  * attribute measured launch times to kernels without mirroring the selection rules. */

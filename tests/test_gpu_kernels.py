@@ -240,16 +240,22 @@ def test_conv_dma_kernel_forced(case):
             assert rel_err(y.float().cpu().numpy(), want.numpy()) < 1e-2, variant
             assert rel_err(y32.cpu().numpy(), want.numpy()) < 1e-3, variant
             assert torch.equal(y, y_small), variant
+        for pixels in (192, 256):     # both tile sizes of the resident-slab kernel (variant 5 is set)
+            _lib.check(L.ymx_set_option(b"halo_pixels", pixels))
+            assert torch.equal(layer(xin, residual=rin), y_small), pixels
+            y32 = layer(xin, residual=rin, out_dtype=torch.float32)
+            assert rel_err(y32.cpu().numpy(), want.numpy()) < 1e-3, pixels
     finally:
         _lib.check(L.ymx_set_option(b"dma_min_tiles", 160))
         _lib.check(L.ymx_set_option(b"dma_variant", 5))
         _lib.check(L.ymx_set_option(b"dma_narrow", 2))
+        _lib.check(L.ymx_set_option(b"halo_pixels", 0))
 
 
 RACE_SHAPES = [   # B, H, W, Cin, Cout, k, stride: every LDS-DMA kernel family at benchmark-sized layers
     (64, 26, 26, 256, 512, 3, 1), (48, 13, 13, 512, 1024, 3, 1), (64, 52, 52, 1024, 512, 1, 1),
     (64, 26, 26, 512, 1024, 3, 2), (64, 208, 208, 32, 64, 3, 1), (48, 104, 104, 64, 128, 3, 1),
-    (64, 104, 104, 128, 64, 1, 1),
+    (64, 104, 104, 128, 64, 1, 1), (64, 52, 52, 128, 256, 3, 1),     # the last one: 256-pixel tiles of the resident-slab kernel
 ]
 
 

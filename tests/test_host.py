@@ -221,10 +221,13 @@ def test_kernel_selection_labels():
     """Which kernel family a layer is routed to, asked of the library (no GPU needed)."""
     assert _label(_conv_op(64, 52, 52, 512, 1024, 3)) == "halo"
     assert _label(_conv_op(64, 76, 76, 512, 1024, 3)) == "dma"        # rows too long for two resident slabs
+    assert _label(_conv_op(64, 13, 13, 512, 1024, 3)) == "halo192"    # 172 tiles of 256 pixels would idle a third of the CUs
+    assert _label(_conv_op(64, 26, 26, 256, 512, 3)) == "halo192"     # 338 tiles: two rounds either way, shorter ones
+    assert _label(_conv_op(64, 26, 26, 512, 1024, 3)) == "halo"
     assert _label(_conv_op(64, 52, 52, 1024, 512, 1)) == "dma4"
     assert _label(_conv_op(64, 26, 26, 512, 1024, 3, stride=2)) == "dma"
     assert _label(_conv_op(1, 13, 13, 512, 1024, 3)) == "igemm"       # too few tiles for the large-tile kernels
-    assert _label(_conv_op(1, 13, 13, 512, 1024, 3, min_tiles=1)) == "halo"
+    assert _label(_conv_op(1, 13, 13, 512, 1024, 3, min_tiles=1)) == "halo192"
     assert _label(_conv_op(64, 208, 208, 32, 64, 3)) == "slab2"
     assert _label(_conv_op(64, 208, 208, 64, 32, 1)) == "dma2"
     # the input-slab kernel is chosen by its real LDS need: 32-channel rows up to 343 pixels,

@@ -149,7 +149,7 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
                 int which = (int)t_opt.variant;
                 if (which == 5) which = conv_halo_eligible(a) ? 5 : ((k == 1 && tiles >= 600) ? 4 : 1);
                 static const char *const names[6] = {"", "dma", "dma2", "", "dma4", "halo"};
-                if (label) { *label = names[which]; return YMX_OK; }
+                if (label) { *label = (which == 5 && conv_halo_tile_pixels(a) == 192) ? "halo192" : names[which]; return YMX_OK; }
                 switch (which) {
                 case 1: return launch_conv_igemm_dma(a, s);
                 case 2: return launch_conv_igemm_dma2(a, s);
@@ -203,6 +203,11 @@ int ymx_set_option(const char *name, long long value) {
     if (!strcmp(name, "dma_stages")) {
         if (value != 3 && value != 4) return fail(YMX_EARG, "set_option: dma_stages must be 3 or 4");
         g_dma2_stages = (int)value;
+        return YMX_OK;
+    }
+    if (!strcmp(name, "halo_pixels")) {
+        if (value != 0 && value != 192 && value != 256) return fail(YMX_EARG, "set_option: halo_pixels must be 0, 192 or 256");
+        g_halo_pixels = (int)value;
         return YMX_OK;
     }
     if (!strcmp(name, "dma_narrow")) {

@@ -27,13 +27,15 @@ typedef __attribute__((ext_vector_type(4))) unsigned int epi_u32x4_t;
 
 // HQMAX = channels transposed at a time: 64 (128-byte output runs, 16 KB image per wave) or 32
 // (64-byte runs, 8 KB per wave: for kernels that trade run length for workgroups per CU).
-template <int NI, int HQMAX = 64>
+// NPX = pixels of the wave tile: 64, or 48 for the three-block tiles of conv_igemm_halo.hip.
+template <int NI, int HQMAX = 64, int NPX = 64>
 struct EpiGeom {
     static constexpr int WQ = NI * 16;                       // channels of the wave tile
     static constexpr int HQ = WQ < HQMAX ? WQ : HQMAX, NH = WQ / HQ;
     static constexpr int SLOTS = HQ / 4, LPP = SLOTS / 2;    // 16-byte slots per fp32 row; lanes per pixel
-    static constexpr int PPI = 64 / LPP, NPASS = 64 / PPI;   // pixels per store instruction; instructions per half
-    static constexpr int LDS_BYTES = 64 * HQ * 4;            // private image of one wave
+    static constexpr int PPI = 64 / LPP, NPASS = NPX / PPI;  // pixels per store instruction; instructions per half
+    static constexpr int LDS_BYTES = NPX * HQ * 4;           // private image of one wave
+    static_assert(NPX % PPI == 0, "whole store instructions");
 };
 
 // True when the 16-byte fast path applies.
@@ -47,10 +49,10 @@ __device__ __forceinline__ bool epi_res_pre(const ConvArgs &a) {
 
 // Issues the shortcut loads of one half: cbase/pbase are the wave tile's first channel and
 // pixel.  Lanes outside the tensor use an out-of-range offset (zeros, no traffic).
-template <int NI, int HQMAX = 64>
+template <int NI, int HQMAX = 64, int NPX = 64>
 __device__ __forceinline__ void epi_load_res(const ConvArgs &a, int half, int cbase, int pbase, int lane,
-                                             epi_u32x4_t (&r)[EpiGeom<NI, HQMAX>::NPASS]) {
-    typedef EpiGeom<NI, HQMAX> G;
+                                             epi_u32x4_t (&r)[EpiGeom<NI, HQMAX, NPX>::NPASS]) {
+    typedef EpiGeom<NI, HQMAX, NPX> G;
     const __amdgpu_buffer_rsrc_t rrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void *)a.res, 0, (int)a.res_bytes, 0x00020000);
     const int co = cbase + half * G::HQ + (lane % G::LPP) * 8;
@@ -67,9 +69,9 @@ __device__ __forceinline__ void epi_load_res(const ConvArgs &a, int half, int cb
 // (128-channel wave tiles) is fetched here, while the first half goes out.
 template <typename OT, int NI, int NJ, int HQMAX = 64>
 __device__ __forceinline__ void epi_run(const ConvArgs &a, f32x4_t (&acc)[NI][NJ], char *tbase, int cbase, int pbase,
-                                        int lane, epi_u32x4_t (&rpre)[EpiGeom<NI, HQMAX>::NH][EpiGeom<NI, HQMAX>::NPASS]) {
-    typedef EpiGeom<NI, HQMAX> G;
-    static_assert(NJ == 4, "wave tiles are 64 pixels wide");
+                                        int lane, epi_u32x4_t (&rpre)[EpiGeom<NI, HQMAX, 16 * NJ>::NH][EpiGeom<NI, HQMAX, 16 * NJ>::NPASS]) {
+    typedef EpiGeom<NI, HQMAX, 16 * NJ> G;
+    static_assert(NJ == 4 || NJ == 3, "wave tiles are 64 or 48 pixels wide");
     constexpr int HQ = G::HQ, NH = G::NH, SLOTS = G::SLOTS, LPP = G::LPP, PPI = G::PPI, NPASS = G::NPASS;
     OT *__restrict__ y = (OT *)a.y;
     const bf16_t *__restrict__ res = (const bf16_t *)a.res;
@@ -112,7 +114,7 @@ __device__ __forceinline__ void epi_run(const ConvArgs &a, f32x4_t (&acc)[NI][NJ
         for (int half = 0; half < NH; ++half) {
             float sc[8], sh[8];
             if constexpr (RES && NH >= 2) {
-                if (half >= 1) epi_load_res<NI, HQMAX>(a, half, cbase, pbase, lane, rpre[half]);   // lands during to_lds
+                if (half >= 1) epi_load_res<NI, HQMAX, 16 * NJ>(a, half, cbase, pbase, lane, rpre[half]);   // lands during to_lds
             }
             load_affine(half, sc, sh);
             to_lds(half);

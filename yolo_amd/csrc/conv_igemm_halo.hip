@@ -37,15 +37,19 @@
 
 namespace ymx {
 
-template <typename OT>
+// NJ = 16-pixel blocks per wave: 4 (256-pixel tiles) or 3 (192-pixel tiles, for layers whose
+// 256-pixel tiles fill the last round of CUs badly).  With three blocks the second pixel half
+// of a wave is one block, so the phases carry 16, 8, 8 and 16 MFMAs; loads, waits and barriers
+// are the same in both forms.
+template <typename OT, int NJ>
 __global__ void __launch_bounds__(512, 2)
 conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const int npieces) {
-    constexpr int TP = 256, TQ = 256;
-    constexpr int WQ = 128, WP = 64;
-    constexpr int NI = WQ / 16, NJ = WP / 16;
+    constexpr int WQ = 128, WP = 16 * NJ;
+    constexpr int TP = 4 * WP, TQ = 256;
+    constexpr int NI = WQ / 16;
     constexpr int WPIECE = 128 * 128;                       // 128 channel rows x 64 bf16
     constexpr unsigned OOB = 0x80000000u;
-    typedef EpiGeom<NI> Epi;
+    typedef EpiGeom<NI, 64, WP> Epi;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -150,6 +154,7 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
             const int j = nh * 2 + jb;
+            if (j >= NJ) continue;
             const bool ok = live && ((fmask[j] >> tap) & 1u);
             const int off = ok ? base + j * 2048 : zero_off;
             bfr[set][jb][0] = *(const uint4 *)(smem + off);
@@ -165,9 +170,16 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
             for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
-                    acc[MH * 4 + ib][NHALF * 2 + jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8_t, af[ib][kk]), __builtin_bit_cast(bf16x8_t, bfr[SET][jb][kk]),
-                        acc[MH * 4 + ib][NHALF * 2 + jb], 0, 0, 0);
+                    if constexpr (NHALF * 2 + 1 < NJ) {
+                        acc[MH * 4 + ib][NHALF * 2 + jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, af[ib][kk]), __builtin_bit_cast(bf16x8_t, bfr[SET][jb][kk]),
+                            acc[MH * 4 + ib][NHALF * 2 + jb], 0, 0, 0);
+                    } else {
+                        if (jb == 0)
+                            acc[MH * 4 + ib][NHALF * 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8_t, af[ib][kk]), __builtin_bit_cast(bf16x8_t, bfr[SET][0][kk]),
+                                acc[MH * 4 + ib][NHALF * 2], 0, 0, 0);
+                    }
         __builtin_amdgcn_s_setprio(0);
     };
     typedef std::integral_constant<int, 0> I0;
@@ -234,7 +246,7 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
     const int cbase = q0 + wq * WQ, pbase = p0 + wp * WP;
     epi_u32x4_t rpre[Epi::NH][Epi::NPASS];
     if (epi_res_pre(a)) {
-        epi_load_res<NI>(a, 0, cbase, pbase, lane, rpre[0]);
+        epi_load_res<NI, 64, WP>(a, 0, cbase, pbase, lane, rpre[0]);
     } else {
 #pragma unroll
         for (int n = 0; n < Epi::NPASS; ++n) rpre[0][n] = epi_u32x4_t{0u, 0u, 0u, 0u};
@@ -254,15 +266,31 @@ bool conv_halo_eligible(const ConvArgs &a) {
     return a.dtype == YMX_BF16 && a.k == 3 && a.stride == 1 && a.Cin % 64 == 0 && a.W <= 59;
 }
 
-template <typename OT>
+thread_local int g_halo_pixels = 0;      // 0: pick the tile per layer; 256 / 192: force it (tuning option "halo_pixels")
+
+// Pixels per tile for a layer: 192 when that shortens the launch.  A launch takes as many
+// rounds as its tiles need on the chip's 256 CUs (one workgroup per CU), and a round of
+// 192-pixel tiles takes about 0.82 of a round of 256-pixel tiles (three quarters of the MFMAs
+// behind the same barriers).  Layers with few tiles gain: 172 tiles of 256 pixels leave a
+// third of the CUs idle for a whole round where 228 tiles of 192 fill the chip for a shorter one.
+int conv_halo_tile_pixels(const ConvArgs &a) {
+    if (g_halo_pixels == 256 || g_halo_pixels == 192) return g_halo_pixels;
+    const long long ntq = (a.Cout + 255) / 256;
+    const long long r256 = (((long long)a.P + 255) / 256 * ntq + 255) / 256;
+    const long long r192 = (((long long)a.P + 191) / 192 * ntq + 255) / 256;
+    return (double)r192 * 0.82 < (double)r256 * 0.97 ? 192 : 256;
+}
+
+template <typename OT, int NJ>
 static int launch_halo_cfg(const ConvArgs &a, hipStream_t s) {
-    const int npieces = (256 + 2 * a.W + 2 + 7) / 8;
+    constexpr int TP = 64 * NJ;
+    const int npieces = (TP + 2 * a.W + 2 + 7) / 8;
     int lds = 2 * npieces * 1024 + 4 * 128 * 128 + 1024;
-    if (lds < 8 * EpiGeom<8>::LDS_BYTES) lds = 8 * EpiGeom<8>::LDS_BYTES;      // the epilogue's transpose images
-    auto kern = conv_igemm_halo_kernel<OT>;
+    if (lds < 8 * EpiGeom<8, 64, 16 * NJ>::LDS_BYTES) lds = 8 * EpiGeom<8, 64, 16 * NJ>::LDS_BYTES;      // the epilogue's transpose images
+    auto kern = conv_igemm_halo_kernel<OT, NJ>;
     static LdsReserve reserved;        // one per kernel instantiation; remembers the devices already set up
     if (const int rc = reserve_lds(reserved, (const void *)kern, 160 * 1024, "conv_igemm_halo")) return rc;
-    const int ntile_p = (a.P + 255) / 256;
+    const int ntile_p = (a.P + TP - 1) / TP;
     const int ntile_q = (a.Cout + 255) / 256;
     const long long grid = (long long)ntile_p * ntile_q;
     if (grid > 0x7fffffffLL) return fail(YMX_EUNSUPPORTED, "conv_igemm_halo: grid too large");
@@ -272,8 +300,12 @@ static int launch_halo_cfg(const ConvArgs &a, hipStream_t s) {
 
 int launch_conv_igemm_halo(const ConvArgs &a, hipStream_t s) {
     if (!conv_halo_eligible(a)) return fail(YMX_EUNSUPPORTED, "conv_igemm_halo: shape not supported");
-    if (a.out_dtype == YMX_BF16) return launch_halo_cfg<bf16_t>(a, s);
-    return launch_halo_cfg<float>(a, s);
+    if (conv_halo_tile_pixels(a) == 192) {
+        if (a.out_dtype == YMX_BF16) return launch_halo_cfg<bf16_t, 3>(a, s);
+        return launch_halo_cfg<float, 3>(a, s);
+    }
+    if (a.out_dtype == YMX_BF16) return launch_halo_cfg<bf16_t, 4>(a, s);
+    return launch_halo_cfg<float, 4>(a, s);
 }
 
 }  // namespace ymx
