@@ -168,6 +168,11 @@ nms_class_kernel(const NmsArgs a) {
     __shared__ u64 s_last, s_last2, s_kmin[4];
     __shared__ u32 s_red[8];
     __shared__ int s_cnt, s_cnt2, s_nkept, s_cutbin;
+    // greedy pass: the 64 candidates of a batch and the boxes kept so far (normalised corners,
+    // area), the candidates' suppression rows and who is dead on arrival
+    __shared__ float4 s_cbox[64], s_kbox[64];
+    __shared__ float s_car[64], s_kar[64];
+    __shared__ u64 s_ckey[64], s_kkey[64], s_row[64], s_dead[4];
 
     const int c = blockIdx.x, b = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63;
@@ -201,10 +206,7 @@ nms_class_kernel(const NmsArgs a) {
     int kstep = nchunk / 4;
     kstep = kstep < 1 ? 1 : (kstep > 8 ? 8 : kstep);
 
-    // wave 0: kept box j lives in lane j
-    float ky1 = 0.f, kx1 = 0.f, ky2 = 0.f, kx2 = 0.f, kar = 0.f;
-    u64 kkey = 0;
-    int nkept = 0;
+    if (t == 0) s_nkept = 0;
     u64 ceil_key = ~0ull;           // keys must be < ceil_key
 
     NSTAMP(0);
@@ -322,41 +324,76 @@ nms_class_kernel(const NmsArgs a) {
             }
         }
         const int n = s_cnt;
-        // wave 0: greedy suppression over `cnt` keys in visiting order; kept boxes accumulate in
-        // the lanes of wave 0 across calls
+        // Greedy suppression over `cnt` keys in visiting order, by the whole workgroup, 64
+        // candidates at a time: every IoU test of a batch runs in parallel -- candidate x box
+        // already kept (each wave takes a quarter of the kept list) and candidate x earlier
+        // candidate (each wave takes 16 rows of the 64 x 64 matrix, one ballot per row) -- and
+        // what is left for one wave to do in order is bit arithmetic: the first live candidate
+        // is kept and its row is cleared from the live mask.  Same decisions as testing one by
+        // one: a candidate is kept iff no box kept before it overlaps it beyond the threshold.
         auto greedy = [&](const u64 *sorted, int cnt) {
-            for (int base = 0; base < cnt && nkept < PC; base += 64) {
-                const int e = base + lane;
-                const bool valid = e < cnt;
-                const u64 key = valid ? sorted[e] : 0ull;
-                const u32 idx = 0xffffffffu - (u32)key;
-                float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid) bx = boxes4[idx];
-                const float y1 = fminf(bx.x, bx.z), x1 = fminf(bx.y, bx.w);
-                const float y2 = fmaxf(bx.x, bx.z), x2 = fmaxf(bx.y, bx.w);
-                const float ar = (y2 - y1) * (x2 - x1);
-                bool alive = valid;
-                for (int j = 0; j < nkept; ++j) {
-                    const float by1 = __shfl(ky1, j), bx1 = __shfl(kx1, j);
-                    const float by2 = __shfl(ky2, j), bx2 = __shfl(kx2, j);
-                    const float bar = __shfl(kar, j);
-                    if (iou_gt(y1, x1, y2, x2, ar, by1, bx1, by2, bx2, bar, a.iou_thr)) alive = false;
+            for (int base = 0; base < cnt; base += 64) {
+                const int nk0 = s_nkept;
+                if (nk0 >= PC) break;
+                if (t < 64) {
+                    const int e = base + t;
+                    const bool valid = e < cnt;
+                    const u64 key = valid ? sorted[e] : 0ull;
+                    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (valid) bx = boxes4[0xffffffffu - (u32)key];
+                    const float y1 = fminf(bx.x, bx.z), x1 = fminf(bx.y, bx.w);
+                    const float y2 = fmaxf(bx.x, bx.z), x2 = fmaxf(bx.y, bx.w);
+                    s_cbox[t] = make_float4(y1, x1, y2, x2);
+                    s_car[t] = (y2 - y1) * (x2 - x1);
+                    s_ckey[t] = key;
                 }
-                u64 m = __ballot(alive);
-                while (m != 0 && nkept < PC) {
-                    const int l = __ffsll((long long)m) - 1;
-                    const float ly1 = __shfl(y1, l), lx1 = __shfl(x1, l);
-                    const float ly2 = __shfl(y2, l), lx2 = __shfl(x2, l);
-                    const float lar = __shfl(ar, l);
-                    const u32 klo = __shfl((u32)key, l), khi = __shfl((u32)(key >> 32), l);
-                    if (lane == nkept) {
-                        ky1 = ly1; kx1 = lx1; ky2 = ly2; kx2 = lx2; kar = lar;
-                        kkey = ((u64)khi << 32) | klo;
+                __syncthreads();
+                {
+                    const float4 cb4 = s_cbox[lane];
+                    const float car = s_car[lane];
+                    const int w = t >> 6;
+                    // against the boxes kept in earlier batches: this wave's quarter of them
+                    bool dead = false;
+                    const int per = (nk0 + 3) >> 2;
+                    for (int j = w * per; j < (w + 1) * per && j < nk0; ++j) {
+                        const float4 kb = s_kbox[j];
+                        if (iou_gt(cb4.x, cb4.y, cb4.z, cb4.w, car, kb.x, kb.y, kb.z, kb.w, s_kar[j], a.iou_thr)) dead = true;
                     }
-                    ++nkept;
-                    if (lane <= l || iou_gt(y1, x1, y2, x2, ar, ly1, lx1, ly2, lx2, lar, a.iou_thr)) alive = false;
-                    m = __ballot(alive);
+                    const u64 dm = __ballot(dead);
+                    if (lane == 0) s_dead[w] = dm;
+                    // within the batch: row i = the later candidates that candidate i suppresses
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = w * 16 + r;
+                        const float4 lb = s_cbox[i];
+                        const bool hit = lane > i && iou_gt(cb4.x, cb4.y, cb4.z, cb4.w, car, lb.x, lb.y, lb.z, lb.w, s_car[i], a.iou_thr);
+                        const u64 rm = __ballot(hit);
+                        if (lane == 0) s_row[i] = rm;
+                    }
                 }
+                __syncthreads();
+                if (t < 64) {
+                    const int nv = cnt - base < 64 ? cnt - base : 64;
+                    u64 alive = (nv == 64 ? ~0ull : ((1ull << nv) - 1ull)) & ~(s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]);
+                    const u64 myrow = s_row[lane];
+                    u64 keptmask = 0;
+                    int nk = nk0;
+                    while (alive != 0 && nk < PC) {
+                        const int i = __ffsll((long long)alive) - 1;
+                        keptmask |= 1ull << i;
+                        ++nk;
+                        const u32 rlo = __shfl((u32)myrow, i), rhi = __shfl((u32)(myrow >> 32), i);
+                        alive &= ~((((u64)rhi) << 32) | rlo);
+                        alive &= ~(1ull << i);
+                    }
+                    if ((keptmask >> lane) & 1ull) {
+                        const int slot = nk0 + __popcll(keptmask & below);
+                        s_kbox[slot] = s_cbox[lane];
+                        s_kar[slot] = s_car[lane];
+                        s_kkey[slot] = s_ckey[lane];
+                    }
+                    if (t == 0) s_nkept = nk;
+                }
+                __syncthreads();
             }
         };
 
@@ -403,7 +440,7 @@ nms_class_kernel(const NmsArgs a) {
                     kmin = s_kmin[w] < kmin ? s_kmin[w] : kmin;
                 }
                 if (omax < omin) {                         // nothing left below lceil: the buffer is used up
-                    if (t == 0) { s_nkept = nkept; s_last = kmin; }   // nkept: wave 0's count
+                    if (t == 0) s_last = kmin;
                     break;
                 }
                 int sh2 = 0;
@@ -445,10 +482,8 @@ nms_class_kernel(const NmsArgs a) {
                     sorted = sel;
                 }
                 __syncthreads();
-                if (t < 64) {
-                    greedy(sorted, nsel);
-                    if (t == 0) { s_nkept = nkept; s_last = kmin; s_last2 = sorted[nsel - 1]; }
-                }
+                greedy(sorted, nsel);
+                if (t == 0) { s_last = kmin; s_last2 = sorted[nsel - 1]; }
                 __syncthreads();
                 if (s_nkept >= PC || cb2 == 0) break;      // done, or every key of the buffer visited
                 lceil = s_last2;
@@ -461,13 +496,8 @@ nms_class_kernel(const NmsArgs a) {
             for (int i = n + t; i < nsort; i += 256) buf[i] = 0;
             __syncthreads();
             bitonic_desc(buf, nsort, t);
-            if (t < 64) {
-                greedy(buf, n);
-                if (t == 0) {
-                    s_nkept = nkept;
-                    s_last = n > 0 ? buf[n - 1] : 0ull;
-                }
-            }
+            greedy(buf, n);
+            if (t == 0) s_last = n > 0 ? buf[n - 1] : 0ull;
         }
         NSTAMP(3);
         __syncthreads();
@@ -480,7 +510,8 @@ nms_class_kernel(const NmsArgs a) {
     }
     if (t < 64) {
         // every slot of the class is written (zero = empty), so the merge reads them unconditionally
-        if (lane < PC) a.kept_keys[((size_t)b * a.C + c) * PC + lane] = lane < nkept ? kkey : 0ull;
+        const int nkept = s_nkept;
+        if (lane < PC) a.kept_keys[((size_t)b * a.C + c) * PC + lane] = lane < nkept ? s_kkey[lane] : 0ull;
         if (lane == 0) a.kept_cnt[b * a.C + c] = nkept;
     }
 }
