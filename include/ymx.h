@@ -263,13 +263,18 @@ int ymx_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dtype
  *   pred   NULL: the decode of conv (decode_train, utils.py:107-131, with stride, xyscale and
  *          the scale's three anchors [3][2], host) is computed inside; else [B,S,S,3,5+C] fp32
  *          dense, of which (cx,cy,w,h,conf) are read, as yolo_loss takes it
- *   label  [B,S,S,3,5+C] fp32 dense (xywh, respond, class probabilities)
- *   bboxes [B,n_boxes,4] fp32 (cx,cy,w,h), unused slots zero (128 in the reference)
+ *   label  [B,S,S,3,5+C] fp32 (xywh, respond, class probabilities), dense within an image;
+ *          label_stride elements from one image to the next (0 = dense)
+ *   bboxes [B,n_boxes,4] fp32 (cx,cy,w,h), unused slots zero (128 in the reference);
+ *          bbox_stride elements from one image to the next (0 = dense).  With the two strides
+ *          both can be read in place from the reference's packed target rows
+ *          [B, S*S*3*(5+C) + 128*4] (losses.py:58-62): no alignment is required of either
  *   out    [3] = (giou_loss, conf_loss, prob_loss); per_image [B][3] per-image sums or NULL
  * input_size = S * stride (losses.py:56).  Deterministic (no float atomics). */
 size_t ymx_yolo_loss_workspace_bytes(int B, int S);
 int ymx_yolo_loss(const float *conv, int conv_ld, const float *pred, const float *label,
-                  const float *bboxes, int B, int S, int C, int n_boxes, float stride, float xyscale,
+                  long long label_stride, const float *bboxes, long long bbox_stride, int B, int S,
+                  int C, int n_boxes, float stride, float xyscale,
                   const float *anchors /* host */, float iou_loss_threshold, float *out,
                   float *per_image, void *workspace, size_t ws_bytes, void *stream);
 

@@ -436,17 +436,20 @@ int ymx_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dtype
 
 size_t ymx_yolo_loss_workspace_bytes(int B, int S) { return yolo_loss_workspace_bytes(B, S); }
 
-int ymx_yolo_loss(const float *conv, int conv_ld, const float *pred, const float *label, const float *bboxes, int B, int S,
-                  int C, int n_boxes, float stride, float xyscale, const float *anchors, float iou_loss_threshold,
+int ymx_yolo_loss(const float *conv, int conv_ld, const float *pred, const float *label, long long label_stride,
+                  const float *bboxes, long long bbox_stride, int B, int S, int C, int n_boxes, float stride, float xyscale, const float *anchors, float iou_loss_threshold,
                   float *out, float *per_image, void *workspace, size_t ws_bytes, void *stream) {
     if (!conv || !label || !bboxes || !anchors || !out) return fail(YMX_EARG, "yolo_loss: null pointer");
     if (B <= 0 || S <= 0 || C <= 0 || n_boxes <= 0) return fail(YMX_EARG, "yolo_loss: non-positive size");
     if (B > 65535) return fail(YMX_EUNSUPPORTED, "yolo_loss: batch above 65535");
     if (conv_ld != 0 && conv_ld < 3 * (5 + C)) return fail(YMX_EARG, "yolo_loss: cell stride %d below 3*(5+C) = %d", conv_ld, 3 * (5 + C));
+    if (label_stride != 0 && label_stride < (long long)3 * S * S * (5 + C)) return fail(YMX_EARG, "yolo_loss: label image stride below one image");
+    if (bbox_stride != 0 && bbox_stride < (long long)4 * n_boxes) return fail(YMX_EARG, "yolo_loss: box image stride below one image");
+    if ((((uintptr_t)conv) | ((uintptr_t)label) | ((uintptr_t)bboxes) | ((uintptr_t)pred)) & 3) return fail(YMX_EARG, "yolo_loss: pointers must be 4-byte aligned");
     const size_t need = yolo_loss_workspace_bytes(B, S);
     if (!workspace || ws_bytes < need) return fail(YMX_EWORKSPACE, "yolo_loss: workspace %zu < %zu bytes", ws_bytes, need);
     if (((uintptr_t)workspace) & 3) return fail(YMX_EARG, "yolo_loss: workspace must be 4-byte aligned");
-    return launch_yolo_loss(conv, conv_ld, pred, label, bboxes, B, S, C, n_boxes, stride, xyscale, anchors, iou_loss_threshold,
+    return launch_yolo_loss(conv, conv_ld, pred, label, label_stride, bboxes, bbox_stride, B, S, C, n_boxes, stride, xyscale, anchors, iou_loss_threshold,
                             out, per_image, workspace, (hipStream_t)stream);
 }
 

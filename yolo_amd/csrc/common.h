@@ -224,8 +224,8 @@ int launch_bbox_iou(const float *b1, const float *b2, float *out, long long n, i
                     hipStream_t s);
 int launch_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dtype, hipStream_t s);
 size_t yolo_loss_workspace_bytes(int B, int S);
-int launch_yolo_loss(const float *conv, int conv_ld, const float *pred, const float *label, const float *bboxes, int B, int S,
-                     int C, int NB, float stride, float xyscale, const float *anchors, float iou_thr, float *out,
+int launch_yolo_loss(const float *conv, int conv_ld, const float *pred, const float *label, long long label_stride,
+                     const float *bboxes, long long bbox_stride, int B, int S, int C, int NB, float stride, float xyscale, const float *anchors, float iou_thr, float *out,
                      float *per_image, void *workspace, hipStream_t s);
 
 // A decode workgroup (256 threads) owns a segment of DEC_SEG consecutive candidates of one

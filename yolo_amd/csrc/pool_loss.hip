@@ -108,8 +108,7 @@ int launch_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dt
 // ---- YOLO loss of one scale, forward ---------------------------------------------------------
 // centre-format IoU and GIoU exactly as /root/reference/utils.py:33-105 (divide_no_nan: 0 when
 // the divisor is 0)
-__device__ __forceinline__ float iou_cxcywh(float ax, float ay, float aw, float ah, float bx, float by, float bw, float bh,
-                                            float *giou) {
+__device__ __forceinline__ float giou_cxcywh(float ax, float ay, float aw, float ah, float bx, float by, float bw, float bh) {
     const float area1 = aw * ah, area2 = bw * bh;
     const float ax0 = ax - aw * 0.5f, ay0 = ay - ah * 0.5f, ax1 = ax + aw * 0.5f, ay1 = ay + ah * 0.5f;
     const float bx0 = bx - bw * 0.5f, by0 = by - bh * 0.5f, bx1 = bx + bw * 0.5f, by1 = by + bh * 0.5f;
@@ -118,30 +117,33 @@ __device__ __forceinline__ float iou_cxcywh(float ax, float ay, float aw, float 
     const float inter = iw * ih;
     const float uni = area1 + area2 - inter;
     const float iou = uni != 0.0f ? inter / uni : 0.0f;
-    if (giou) {
-        const float ew = fmaxf(ax1, bx1) - fminf(ax0, bx0), eh = fmaxf(ay1, by1) - fminf(ay0, by0);
-        const float earea = ew * eh;
-        *giou = iou - (earea != 0.0f ? (earea - uni) / earea : 0.0f);
-    }
-    return iou;
+    const float ew = fmaxf(ax1, bx1) - fminf(ax0, bx0), eh = fmaxf(ay1, by1) - fminf(ay0, by0);
+    const float earea = ew * eh;
+    return iou - (earea != 0.0f ? (earea - uni) / earea : 0.0f);
 }
 
 // tf.nn.sigmoid_cross_entropy_with_logits: max(x, 0) - x z + log(1 + exp(-|x|))
 __device__ __forceinline__ float sce_logits(float z, float x) {
-    return fmaxf(x, 0.0f) - x * z + log1pf(expf(-fabsf(x)));
+    return fmaxf(x, 0.0f) - x * z + __logf(1.0f + __expf(-fabsf(x)));
 }
 
-// One workgroup per 64 candidates (row, col, anchor order) of one image.  The candidates'
-// rows of `conv` and `label` are staged in LDS; lane = candidate in all four waves; wave q
-// sums the class cross-entropies of class slice q and takes the max IoU over ground-truth
-// boxes [q*NB/4, (q+1)*NB/4); wave 0 then forms the three loss terms and reduces them over
-// its 64 lanes into one partial per workgroup (summed per image, in order, by the second
-// kernel: no float atomics, the result is reproducible).
+// One wavefront per 64 candidates (row, col, anchor order) of one image, four per workgroup.
+// A lane reads only the five leading values of its candidate's `conv` and `label` rows; the
+// class parts of the two rows (80 of 85 values at 80 classes) are read -- by the whole wave,
+// coalesced -- only for candidates whose `respond` label is non-zero, since the reference
+// multiplies the class cross-entropy by it: a map with few objects is not read in full.
+// Wave 0 first compacts the image's ground-truth boxes into LDS (all-zero rows of the
+// 128-slot buffer have IoU 0 with everything and cannot change the maximum, which starts at
+// 0 as IoU is never negative).  The background mask needs only "max IoU < threshold",
+// evaluated as inter < threshold * union per box: no division.  Each wave reduces its three
+// loss terms over its lanes into one partial (summed per image in a fixed order by the
+// second kernel: no float atomics, the result is reproducible).
 struct LossArgs {
     const float *conv, *pred, *label, *bboxes;
     float *partial;              // [B][nseg][3]
     int B, S, C, NB, nseg;
     int conv_ld;                 // elements from one grid cell to the next in conv (>= 3*(5+C))
+    long long label_stride, bbox_stride;   // elements from one image to the next
     float stride, xyscale, anchor[3][2];
     float input_size, iou_thr;
 };
@@ -149,101 +151,139 @@ struct LossArgs {
 __global__ void __launch_bounds__(256)
 yolo_loss_kernel(const LossArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *sbox = (float *)smem_raw;                 // [NB][4] compacted
+    int *scnt = (int *)(sbox + 4 * a.NB);
     const int D = 5 + a.C;
-    const int stage_words = 64 * D + 22 * (a.conv_ld - 3 * D);
-    float *sconv = (float *)smem_raw;                // span of conv rows, padding included
-    float *slabel = sconv + stage_words;             // [64][D]
-    float *sbox = slabel + 64 * D;                   // [NB][4]
-    float *sred = sbox + 4 * a.NB;                   // [2][4][64]: class sums, max IoU
     const int t = threadIdx.x, lane = t & 63;
     const int q = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int seg = blockIdx.x, b = blockIdx.y;
+    const int seg = blockIdx.x * 4 + q, b = blockIdx.y;
     const int Ns = 3 * a.S * a.S;
     const int c0 = seg * 64;
-    int nvalid = Ns - c0;
-    nvalid = nvalid > 64 ? 64 : nvalid;
-    const int cell0 = c0 / 3, a0 = c0 - cell0 * 3;
-    const int cl = c0 + nvalid - 1, cellL = cl / 3;
-    const int span = (cellL - cell0) * a.conv_ld + (cl - cellL * 3 + 1) * D - a0 * D;
-    const float *csrc = a.conv + ((size_t)b * a.S * a.S + cell0) * a.conv_ld + a0 * D;
-    const float *lsrc = a.label + ((size_t)b * Ns + c0) * D;
-    for (int i = t; i < span; i += 256) sconv[i] = csrc[i];
-    for (int i = t; i < nvalid * D; i += 256) slabel[i] = lsrc[i];
-    for (int i = t; i < 4 * a.NB; i += 256) sbox[i] = a.bboxes[(size_t)b * a.NB * 4 + i];
-    __syncthreads();
-
-    const bool live = lane < nvalid;
     const int cme = c0 + lane, cellm = cme / 3, an = cme - cellm * 3;
-    const float *row = sconv + (cellm - cell0) * a.conv_ld + an * D - a0 * D;
-    const float *lab = slabel + lane * D;
-    float px = 0.f, py = 0.f, pw = 0.f, ph = 0.f, pconf = 0.f;
-    float csum = 0.f, miou = 0.f;
+    const bool live = cme < Ns;
+    // the candidate's own values first: the loads are in flight while wave 0 compacts the boxes
+    const float *row = a.conv + ((size_t)b * a.S * a.S + cellm) * a.conv_ld + an * D;
+    const float *lab = a.label + (size_t)b * a.label_stride + (size_t)cme * D;
+    float r[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, l[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, pr[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (live) {
-        if (a.pred) {
-            const float *pr = a.pred + ((size_t)b * Ns + cme) * D;
-            px = pr[0]; py = pr[1]; pw = pr[2]; ph = pr[3]; pconf = pr[4];
-        } else {
-            const int col = cellm % a.S, rw = cellm / a.S;
-            const float half = 0.5f * (a.xyscale - 1.0f);
-            px = ((1.0f / (1.0f + expf(-row[0]))) * a.xyscale - half + (float)col) * a.stride;
-            py = ((1.0f / (1.0f + expf(-row[1]))) * a.xyscale - half + (float)rw) * a.stride;
-            pw = expf(row[2]) * a.anchor[an][0];
-            ph = expf(row[3]) * a.anchor[an][1];
-            pconf = 1.0f / (1.0f + expf(-row[4]));
-        }
-        const int cper = (a.C + 3) / 4;
-        for (int c = q * cper; c < (q + 1) * cper && c < a.C; ++c) csum += sce_logits(lab[5 + c], row[5 + c]);
-        const int bper = (a.NB + 3) / 4;
-        for (int j = q * bper; j < (q + 1) * bper && j < a.NB; ++j) {
-            const float v = iou_cxcywh(px, py, pw, ph, sbox[4 * j], sbox[4 * j + 1], sbox[4 * j + 2], sbox[4 * j + 3], nullptr);
-            miou = (j == q * bper) ? v : fmaxf(miou, v);
-        }
-        if (q * bper >= a.NB) miou = -INFINITY;         // this wave had no box: neutral in the max
-    }
-    sred[q * 64 + lane] = csum;
-    sred[256 + q * 64 + lane] = miou;
-    __syncthreads();
-    if (q == 0) {
-        float lg = 0.f, lc = 0.f, lp = 0.f;
-        if (live) {
-            const float prob_sum = (sred[lane] + sred[64 + lane]) + (sred[128 + lane] + sred[192 + lane]);
-            const float max_iou = fmaxf(fmaxf(sred[256 + lane], sred[320 + lane]), fmaxf(sred[384 + lane], sred[448 + lane]));
-            const float respond = lab[4];
-            float giou;
-            iou_cxcywh(px, py, pw, ph, lab[0], lab[1], lab[2], lab[3], &giou);
-            const float scale = 2.0f - 1.0f * lab[2] * lab[3] / (a.input_size * a.input_size);
-            lg = respond * scale * (1.0f - giou);
-            const float bgd = (1.0f - respond) * (max_iou < a.iou_thr ? 1.0f : 0.0f);
-            const float d = respond - pconf;
-            const float bce = sce_logits(respond, row[4]);
-            lc = (d * d) * (respond * bce + bgd * bce);
-            lp = respond * prob_sum;
-        }
 #pragma unroll
-        for (int dl = 32; dl > 0; dl >>= 1) {
-            lg += __shfl_xor(lg, dl);
-            lc += __shfl_xor(lc, dl);
-            lp += __shfl_xor(lp, dl);
+        for (int i = 0; i < 5; ++i) { r[i] = row[i]; l[i] = lab[i]; }
+        if (a.pred) {
+            const float *pp = a.pred + ((size_t)b * Ns + cme) * D;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) pr[i] = pp[i];
         }
-        if (lane == 0) {
-            float *o = a.partial + ((size_t)b * a.nseg + seg) * 3;
-            o[0] = lg; o[1] = lc; o[2] = lp;
+    }
+    if (q == 0) {
+        int n = 0;
+        for (int j0 = 0; j0 < a.NB; j0 += 64) {
+            const int j = j0 + lane;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < a.NB) {
+                const float *g = a.bboxes + (size_t)b * a.bbox_stride + (size_t)j * 4;
+                v = make_float4(g[0], g[1], g[2], g[3]);
+            }
+            const bool nz = (v.x != 0.0f) | (v.y != 0.0f) | (v.z != 0.0f) | (v.w != 0.0f);
+            const unsigned long long m = __ballot(nz);
+            if (nz) *(float4 *)(sbox + 4 * (n + __popcll(m & ((1ull << lane) - 1ull)))) = v;
+            n += __popcll(m);
         }
+        if (lane == 0) *scnt = n;
+    }
+    __syncthreads();
+    if (seg >= a.nseg) return;
+    const int nbox = *scnt;
+
+    float px, py, pw, ph, pconf;
+    if (a.pred) {
+        px = pr[0]; py = pr[1]; pw = pr[2]; ph = pr[3]; pconf = pr[4];
+    } else {
+        const int col = cellm % a.S, rw = cellm / a.S;
+        const float half = 0.5f * (a.xyscale - 1.0f);
+        px = ((1.0f / (1.0f + __expf(-r[0]))) * a.xyscale - half + (float)col) * a.stride;
+        py = ((1.0f / (1.0f + __expf(-r[1]))) * a.xyscale - half + (float)rw) * a.stride;
+        pw = __expf(r[2]) * a.anchor[an][0];
+        ph = __expf(r[3]) * a.anchor[an][1];
+        pconf = 1.0f / (1.0f + __expf(-r[4]));
+    }
+    // class cross-entropy of the responsible candidates, one at a time by the whole wave
+    float prob_sum = 0.f;
+    unsigned long long m = __ballot(live && l[4] != 0.0f);
+    while (m) {
+        const int who = __builtin_ctzll(m);
+        m &= m - 1;
+        const int cw = c0 + who, cellw = cw / 3, aw = cw - cellw * 3;
+        const float *rr = a.conv + ((size_t)b * a.S * a.S + cellw) * a.conv_ld + aw * D + 5;
+        const float *ll = a.label + (size_t)b * a.label_stride + (size_t)cw * D + 5;
+        float s = 0.f;
+        for (int c = lane; c < a.C; c += 64) s += sce_logits(ll[c], rr[c]);
+#pragma unroll
+        for (int dl = 32; dl > 0; dl >>= 1) s += __shfl_xor(s, dl);
+        if (lane == who) prob_sum = s;
+    }
+    // background test against the ground-truth boxes
+    bool hit = false;
+    {
+        const float area1 = pw * ph;
+        const float ax0 = px - pw * 0.5f, ay0 = py - ph * 0.5f, ax1 = px + pw * 0.5f, ay1 = py + ph * 0.5f;
+        for (int j = 0; j < nbox; ++j) {
+            const float4 g = *(const float4 *)(sbox + 4 * j);           // same address in every lane: a broadcast
+            const float bx0 = g.x - g.z * 0.5f, by0 = g.y - g.w * 0.5f, bx1 = g.x + g.z * 0.5f, by1 = g.y + g.w * 0.5f;
+            const float iw = fmaxf(fminf(ax1, bx1) - fmaxf(ax0, bx0), 0.0f);
+            const float ih = fmaxf(fminf(ay1, by1) - fmaxf(ay0, by0), 0.0f);
+            const float inter = iw * ih;
+            const float uni = area1 + g.z * g.w - inter;
+            hit |= (uni != 0.0f) & !(inter < a.iou_thr * uni);
+        }
+    }
+    float lg = 0.f, lc = 0.f, lp = 0.f;
+    if (live) {
+        const float respond = l[4];
+        const float giou = giou_cxcywh(px, py, pw, ph, l[0], l[1], l[2], l[3]);
+        const float scale = 2.0f - 1.0f * l[2] * l[3] / (a.input_size * a.input_size);
+        lg = respond * scale * (1.0f - giou);
+        const float bgd = (1.0f - respond) * (hit ? 0.0f : 1.0f);
+        const float d = respond - pconf;
+        const float bce = sce_logits(respond, r[4]);
+        lc = (d * d) * (respond * bce + bgd * bce);
+        lp = respond * prob_sum;
+    }
+#pragma unroll
+    for (int dl = 32; dl > 0; dl >>= 1) {
+        lg += __shfl_xor(lg, dl);
+        lc += __shfl_xor(lc, dl);
+        lp += __shfl_xor(lp, dl);
+    }
+    if (lane == 0) {
+        float *o = a.partial + ((size_t)b * a.nseg + seg) * 3;
+        o[0] = lg; o[1] = lc; o[2] = lp;
     }
 }
 
-// Sums the workgroup partials of every image in segment order, then averages over the
-// batch in image order: per_image [B][3] (may be null) and out [3] = (giou, conf, prob).
+// Sums the workgroup partials of every image (16 lanes per image, each a strided share in
+// segment order, then a fixed shuffle tree), then averages over the batch in image order:
+// per_image [B][3] (may be null) and out [3] = (giou, conf, prob).
 __global__ void __launch_bounds__(256)
 yolo_loss_reduce_kernel(const float *__restrict__ partial, float *__restrict__ per_image, float *__restrict__ out,
                         float *__restrict__ scratch, int B, int nseg) {
-    const int t = threadIdx.x;
-    for (int b = t; b < B; b += 256) {
+    const int t = threadIdx.x, sub = t & 15;
+    for (int b0 = 0; b0 < B; b0 += 16) {
+        const int b = b0 + (t >> 4);
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        const float *p = partial + (size_t)b * nseg * 3;
-        for (int i = 0; i < nseg; ++i) { s0 += p[3 * i]; s1 += p[3 * i + 1]; s2 += p[3 * i + 2]; }
-        scratch[3 * b] = s0; scratch[3 * b + 1] = s1; scratch[3 * b + 2] = s2;
-        if (per_image) { per_image[3 * b] = s0; per_image[3 * b + 1] = s1; per_image[3 * b + 2] = s2; }
+        if (b < B) {
+            const float *p = partial + (size_t)b * nseg * 3;
+            for (int i = sub; i < nseg; i += 16) { s0 += p[3 * i]; s1 += p[3 * i + 1]; s2 += p[3 * i + 2]; }
+        }
+#pragma unroll
+        for (int dl = 8; dl > 0; dl >>= 1) {
+            s0 += __shfl_xor(s0, dl);
+            s1 += __shfl_xor(s1, dl);
+            s2 += __shfl_xor(s2, dl);
+        }
+        if (b < B && sub == 0) {
+            scratch[3 * b] = s0; scratch[3 * b + 1] = s1; scratch[3 * b + 2] = s2;
+            if (per_image) { per_image[3 * b] = s0; per_image[3 * b + 1] = s1; per_image[3 * b + 2] = s2; }
+        }
     }
     __threadfence_block();
     __syncthreads();
@@ -260,8 +300,8 @@ size_t yolo_loss_workspace_bytes(int B, int S) {
     return ((size_t)B * nseg * 3 + (size_t)B * 3) * 4;
 }
 
-int launch_yolo_loss(const float *conv, int conv_ld, const float *pred, const float *label, const float *bboxes, int B, int S,
-                     int C, int NB, float stride, float xyscale, const float *anchors, float iou_thr, float *out,
+int launch_yolo_loss(const float *conv, int conv_ld, const float *pred, const float *label, long long label_stride,
+                     const float *bboxes, long long bbox_stride, int B, int S, int C, int NB, float stride, float xyscale, const float *anchors, float iou_thr, float *out,
                      float *per_image, void *workspace, hipStream_t s) {
     LossArgs a;
     a.conv = conv; a.pred = pred; a.label = label; a.bboxes = bboxes;
@@ -269,14 +309,15 @@ int launch_yolo_loss(const float *conv, int conv_ld, const float *pred, const fl
     a.B = B; a.S = S; a.C = C; a.NB = NB;
     a.nseg = (3 * S * S + 63) / 64;
     a.conv_ld = conv_ld > 0 ? conv_ld : 3 * (5 + C);
+    a.label_stride = label_stride > 0 ? label_stride : (long long)3 * S * S * (5 + C);
+    a.bbox_stride = bbox_stride > 0 ? bbox_stride : (long long)4 * NB;
     a.stride = stride; a.xyscale = xyscale;
     for (int i = 0; i < 6; ++i) (&a.anchor[0][0])[i] = anchors[i];
     a.input_size = (float)S * stride;
     a.iou_thr = iou_thr;
-    const int D = 5 + C;
-    const size_t lds = ((size_t)64 * D + 22 * (size_t)(a.conv_ld - 3 * D) + (size_t)64 * D + 4 * (size_t)NB + 512) * 4;
-    if (lds > 64 * 1024) return fail(YMX_EUNSUPPORTED, "yolo_loss: %d classes / %d boxes / cell stride %d need %zu bytes of LDS", C, NB, a.conv_ld, lds);
-    hipLaunchKernelGGL(yolo_loss_kernel, dim3(a.nseg, B), dim3(256), lds, s, a);
+    const size_t lds = (size_t)NB * 16 + 16;
+    if (lds > 64 * 1024) return fail(YMX_EUNSUPPORTED, "yolo_loss: %d ground-truth slots per image need %zu bytes of LDS", NB, lds);
+    hipLaunchKernelGGL(yolo_loss_kernel, dim3((a.nseg + 3) / 4, B), dim3(256), lds, s, a);
     int rc = check_launch("yolo_loss");
     if (rc) return rc;
     float *scratch = a.partial + (size_t)B * a.nseg * 3;

@@ -16,7 +16,7 @@ from .utils import _anchors_array
 N_BOXES = 128          # ground-truth slots per image in the target layout (losses.py:62)
 
 
-def _launch(conv5, conv_ld, pred5, label5, bboxes, stride, xyscale, anchors3x2, iou_loss_threshold, per_image=False):
+def _launch(conv5, conv_ld, pred5, label5, label_stride, bboxes, bbox_stride, stride, xyscale, anchors3x2, iou_loss_threshold, per_image=False):
     B, S, C = conv5.shape[0], conv5.shape[1], conv5.shape[4] - 5
     dev = conv5.device
     out = torch.empty((3,), device=dev, dtype=torch.float32)
@@ -25,8 +25,8 @@ def _launch(conv5, conv_ld, pred5, label5, bboxes, stride, xyscale, anchors3x2, 
     ws_bytes = L.ymx_yolo_loss_workspace_bytes(B, S)
     ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
     anc = (ctypes.c_float * 6)(*[float(v) for v in np.asarray(anchors3x2, np.float32).reshape(-1)[:6]])
-    _lib.launch("ymx_yolo_loss", out, _lib.ptr(conv5), int(conv_ld), _lib.ptr(pred5), _lib.ptr(label5), _lib.ptr(bboxes),
-                B, S, C, int(bboxes.shape[1]), float(stride), float(xyscale), anc, float(iou_loss_threshold),
+    _lib.launch("ymx_yolo_loss", out, _lib.ptr(conv5), int(conv_ld), _lib.ptr(pred5), _lib.ptr(label5), int(label_stride),
+                _lib.ptr(bboxes), int(bbox_stride), B, S, C, int(bboxes.shape[1]), float(stride), float(xyscale), anc, float(iou_loss_threshold),
                 _lib.ptr(out), _lib.ptr(per), _lib.ptr(ws), ws_bytes)
     return out, per
 
@@ -51,7 +51,7 @@ def yolo_loss(pred, conv, label, bboxes, input_size, iou_loss_threshold):
     if bx.dim() != 3 or bx.shape[0] != conv5.shape[0] or bx.shape[2] != 4:
         raise ValueError("bboxes: expected [B,NB,4], got %s" % (tuple(bx.shape),))
     S = conv5.shape[1]
-    out, _ = _launch(conv5, 0, pred5, label5, bx, float(input_size) / S, 1.0, np.ones((3, 2), np.float32),
+    out, _ = _launch(conv5, 0, pred5, label5, 0, bx, 0, float(input_size) / S, 1.0, np.ones((3, 2), np.float32),
                      iou_loss_threshold)
     return out[0], out[1], out[2]
 
@@ -71,10 +71,11 @@ def loss_at_scale(target, output, scale, num_classes, strides, iou_loss_threshol
         raise ValueError("target: expected [B, %d], got %s" % (split + N_BOXES * 4, tuple(target.shape)))
     out5 = output.float().contiguous().view(B, S, S, 3, D)
     tgt = target.float().contiguous()
-    labels = tgt[:, :split].contiguous().view(B, S, S, 3, D)
-    bboxes = tgt[:, split:].contiguous().view(B, N_BOXES, 4)
+    # labels and boxes are read in place from the packed target rows (image stride = row length)
+    labels = tgt[:, :split]
+    bboxes = tgt[:, split:].unflatten(1, (N_BOXES, 4))
     anc = _anchors_array(anchors)[scale]
-    out, _ = _launch(out5, 0, None, labels, bboxes, strides[scale], xyscale[scale], anc, iou_loss_threshold)
+    out, _ = _launch(out5, 0, None, labels, tgt.shape[1], bboxes, tgt.shape[1], strides[scale], xyscale[scale], anc, iou_loss_threshold)
     return out if terms else out.sum()
 
 
