@@ -476,6 +476,20 @@ def test_auto_cut_is_timed_once_and_exact():
         Detector(num_classes=C, split=(4, 0))
 
 
+def test_prepare_plans_ahead_of_the_first_forward():
+    """Detector.prepare does the planning (buffers, timed cut) that the first forward would
+    do, reports what it kept, and the forward that follows reuses that plan."""
+    from yolo_amd import Detector
+    det = Detector(num_classes=3, dtype=torch.bfloat16, seed=2).to(DEV)
+    info = det.prepare(4, 96)
+    assert info["sub_batches"] == [4] and info["bytes"] > 4 * 96 * 96 * 32 * 2
+    plans = dict(det._plans)
+    out = det(_image(4, 96).to(DEV))
+    assert out[0].shape == (4, 32, 4) and dict(det._plans) == plans
+    with pytest.raises(ValueError):
+        det.prepare(4, 100)
+
+
 @pytest.mark.parametrize("S,B", [(416, 64), (608, 32)])
 def test_benchmark_batch_properties(S, B):
     """The benchmark configurations themselves (416x416 batch 64 and 608x608 batch 32 per

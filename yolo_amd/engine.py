@@ -395,6 +395,22 @@ class Detector(nn.Module):
         for part in parts[1:]:
             torch.cuda.current_stream().wait_event(part.done)
 
+    def prepare(self, batch, size, x_dtype=torch.float32, device=None):
+        """Plans the program for [batch, size, size, 3] inputs now instead of inside the first
+        forward: allocates the activation buffers (one per layer output, about 100 MB per
+        416x416 image in bf16) and, with split="auto", times the candidate cuts of the batch
+        (about 0.3 s at batch 64; every candidate but the whole-batch plan and the best so
+        far is released as soon as it has been timed).  Returns the chosen sub-batch sizes
+        and the bytes of device memory the plan keeps."""
+        if size % 32:
+            raise ValueError("image side must be a multiple of 32, got %d" % size)
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("yolo_amd: no CPU fallback; prepare() needs a GPU device")
+        plan = self._plan(int(batch), int(size), x_dtype, device)
+        kept = sum(t.numel() * t.element_size() for part in plan.parts for t in part.keep if torch.is_tensor(t))
+        return {"sub_batches": [part.B for part in plan.parts], "bytes": int(kept)}
+
     def forward_heads(self, x):
         """images [B,S,S,3] -> (sbbox, mbbox, lbbox) raw conv maps (plan-owned buffers)."""
         x = self._check_input(x)
