@@ -160,7 +160,7 @@ __device__ __forceinline__ float4 load_chunk(const float *__restrict__ col, int 
     return i0 < M ? *(const float4 *)(col + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-__global__ void __launch_bounds__(256)      // ~108 registers: four workgroups per CU; capping them for more spills into the streaming loops
+__global__ void __launch_bounds__(256, 4)   // four workgroups per CU (128 registers); a fifth does not pay and three lose 8 %
 nms_class_kernel(const NmsArgs a) {
     __shared__ __attribute__((aligned(16))) u64 buf[NMS_BUF + 8];
     __shared__ int hist[NMS_BINS];
@@ -251,13 +251,23 @@ nms_class_kernel(const NmsArgs a) {
         // ---- key pass, fast form: no barrier inside the loop.  Keys above the floor are
         // appended (ballot + one LDS atomic per wave); positions beyond the buffer are counted
         // but not stored, and if that happened the pass is repeated in the careful form below.
+        // The next four chunks are requested before the current four are looked at, so a
+        // workgroup always has loads in flight; a 16-byte group of scores is examined
+        // element by element only if some lane's group holds a score at or above the floor
+        // (one float compare per element; a superset of the exact key test that follows).
         {
-            for (int j0 = 0; j0 < nchunk; j0 += 4) {
-                float4 v[4];                               // four independent loads in flight per thread
+            const float floor_f = cut ? unord_bits((u32)((floor_key + 1ull) >> 32)) : -INFINITY;
+            const float qthr = fmaxf(floor_f, a.score_thr);
+            float4 v[4], nx[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = load_chunk(col, (j0 + u) * NMS_CHUNK + t * 4, M);
+            for (int u = 0; u < 4; ++u) v[u] = load_chunk(col, u * NMS_CHUNK + t * 4, M);
+            for (int j0 = 0; j0 < nchunk; j0 += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) nx[u] = load_chunk(col, (j0 + 4 + u) * NMS_CHUNK + t * 4, M);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
+                    const float mx = fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w));
+                    if (__ballot(mx >= qthr) == 0ull) continue;
                     const int i0 = (j0 + u) * NMS_CHUNK + t * 4;
                     const float sv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
@@ -277,6 +287,8 @@ nms_class_kernel(const NmsArgs a) {
                         }
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = nx[u];
             }
         }
         __syncthreads();
