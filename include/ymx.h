@@ -28,7 +28,7 @@ extern "C" {
 
 #define YMX_VERSION 100
 
-enum { YMX_F32 = 0, YMX_BF16 = 1 };
+enum { YMX_F32 = 0, YMX_BF16 = 1, YMX_U8 = 2 /* image entry points only */ };
 enum { YMX_ACT_NONE = 0, YMX_ACT_LEAKY = 1, YMX_ACT_MISH = 2 };
 enum {
     YMX_OK = 0,
@@ -277,6 +277,31 @@ int ymx_yolo_loss(const float *conv, int conv_ld, const float *pred, const float
                   int C, int n_boxes, float stride, float xyscale,
                   const float *anchors /* host */, float iou_loss_threshold, float *out,
                   float *per_image, void *workspace, size_t ws_bytes, void *stream);
+
+/* ---- letterbox resize ---------------------------------------------------------
+ * Replaces the image half of image_preprocess (utils.py:16-26): the image is resized by
+ * scale = min(target/W, target/H) (bilinear, half-pixel centres, edges replicated: the
+ * arithmetic of cv2.resize's default INTER_LINEAR on float images; 8-bit sources are
+ * converted to float first, where OpenCV itself would use 11-bit fixed-point weights),
+ * centred in a target x target square filled with 128, and divided by 256.
+ *   images [B,H,W,3] fp32 or 8-bit (in_dtype YMX_F32 / YMX_U8), out [B,target,target,3]
+ *   fp32 or bf16.  literal != 0 reproduces utils.py:21,25 as written: cv2.resize takes
+ *   (width, height) but is handed (new_height, new_width), so a non-square image comes out
+ *   with new_width rows and new_height columns and is pasted at rows pad_width.
+ * The box half of image_preprocess is host arithmetic (dataset.letterbox_boxes). */
+int ymx_letterbox(const void *images, int in_dtype, int B, int H, int W, void *out, int out_dtype,
+                  int target, int literal, void *stream);
+
+/* ---- box outlines -------------------------------------------------------------
+ * Replaces the rectangle drawing of draw_bbox (utils.py:216-231) on a batch: for image b
+ * the first valid[b] detections (boxes [B,max_boxes,4] normalised (ymin,xmin,ymax,xmax),
+ * classes [B,max_boxes] fp32, as ymx_nms_combined writes them) are outlined in order, in
+ * colors[class] (device, [C][3] 8-bit), `thickness` pixels wide (values below 1 draw 1),
+ * on images [B,H,W,3] 8-bit, in place.  Corners are (int)(coordinate * size); a later box
+ * paints over an earlier one.  Text labels (cv2.putText) are not drawn. */
+int ymx_draw_boxes(unsigned char *images, int B, int H, int W, const float *boxes,
+                   const float *classes, const int *valid, int max_boxes,
+                   const unsigned char *colors, int C, int thickness, void *stream);
 
 /* ---- label assignment ---------------------------------------------------------
  * Replaces WIDERDataset.preprocess_true_boxes (dataset.py:387-482) for a batch: every

@@ -175,3 +175,72 @@ def test_assign_labels_vs_oracle(C, size, literal):
     val = L.loss_at_scale(tg[2], out, 2, C, cfg["strides"], 0.5, cfg["xyscale"], cfg["anchors"], terms=True)
     want = LN.loss_at_scale(tg[2].cpu().numpy(), out.cpu().numpy(), 2, C, P.STRIDES, 0.5, P.XYSCALE, P.ANCHORS)[1]
     np.testing.assert_allclose(val.cpu().numpy().astype(np.float64), np.array(want, np.float64), rtol=1e-3)
+
+
+@pytest.mark.parametrize("shape,target,literal", [((37, 53), 64, False), ((37, 53), 64, True), ((480, 640), 416, False),
+                                                  ((300, 200), 416, True), ((416, 416), 416, False), ((5, 3), 32, False)])
+def test_letterbox_bit_exact_vs_oracle(shape, target, literal):
+    from oracle import image_np as IM
+    from yolo_amd import utils as U
+    rng = np.random.default_rng(shape[0] * 7 + target)
+    B = 2
+    img8 = rng.integers(0, 256, (B, shape[0], shape[1], 3)).astype(np.uint8)
+    imgf = rng.uniform(0, 255, (B, shape[0], shape[1], 3)).astype(np.float32)
+    boxes = np.array([[3.0, 4.0, 20.0, 30.0, 1.0]], np.float64)
+    for src in (img8, imgf):
+        want = np.stack([IM.letterbox(src[b], target, literal) for b in range(B)])
+        got, bx = U.image_preprocess(torch.from_numpy(src).to(DEV), boxes, target, literal=literal)
+        assert got.shape == (B, target, target, 3) and got.dtype == torch.float32
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        g16, _ = U.image_preprocess(torch.from_numpy(src).to(DEV), None, target, literal=literal, dtype=torch.bfloat16)
+        assert torch.equal(g16.cpu(), torch.from_numpy(want).to(torch.bfloat16))
+    # one image, and the box half of the function (utils.py:29-30)
+    one, bx = U.image_preprocess(torch.from_numpy(img8[0]).to(DEV), boxes, target, literal=literal)
+    np.testing.assert_array_equal(one.cpu().numpy(), IM.letterbox(img8[0], target, literal))
+    scale = min(target / shape[1], target / shape[0])
+    pad_h, pad_w = (target - int(scale * shape[0])) // 2, (target - int(scale * shape[1])) // 2
+    np.testing.assert_allclose(bx[0], [3 * scale + pad_w, 4 * scale + pad_h, 20 * scale + pad_w, 30 * scale + pad_h, 1.0])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        U.image_preprocess(torch.from_numpy(img8), None, target)
+
+
+@pytest.mark.parametrize("thickness", [1, 2, 3, None])
+def test_draw_boxes_vs_oracle(thickness):
+    from oracle import image_np as IM
+    from yolo_amd import utils as U
+    rng = np.random.default_rng(3)
+    B, H, W, M, C = 3, 96, 128, 12, 5
+    imgs = rng.integers(0, 256, (B, H, W, 3)).astype(np.uint8)
+    lo = rng.uniform(0, 0.7, (B, M, 2)).astype(np.float32)
+    hi = np.minimum(lo + rng.uniform(0.02, 0.5, (B, M, 2)).astype(np.float32), 1.0).astype(np.float32)
+    boxes = np.concatenate([lo, hi], -1)                       # (ymin, xmin, ymax, xmax), overlapping freely
+    boxes[0, 1] = boxes[0, 0]                                  # identical boxes of different classes: the later wins
+    classes = rng.integers(0, C, (B, M)).astype(np.float32)
+    classes[1, 2] = C                                          # out of range: skipped
+    valid = np.array([M, 0, 7], np.int32)
+    t = int(0.6 * (H + W) / 600) if thickness is None else thickness
+    want = np.stack([IM.draw_boxes(imgs[b], boxes[b], classes[b], valid[b], C, t) for b in range(B)])
+    d = torch.from_numpy(imgs).to(DEV)
+    out = U.draw_boxes(d, torch.from_numpy(boxes).to(DEV), torch.from_numpy(classes).to(DEV), torch.from_numpy(valid).to(DEV),
+                       C, thickness)
+    assert out.data_ptr() == d.data_ptr()
+    np.testing.assert_array_equal(d.cpu().numpy(), want)
+    assert (want[1] == imgs[1]).all() and (want[0] != imgs[0]).any()
+
+
+def test_draw_bbox_end_to_end():
+    """draw_bbox = bbox_nms on the model output + outlines (utils.py:197-242): the drawn images
+    equal the oracle's drawing of the detections the GPU NMS returns."""
+    from oracle import image_np as IM
+    from yolo_amd import utils as U
+    C, B = 3, 2
+    g = torch.Generator().manual_seed(0)
+    heads = [(torch.randn(B, s, s, 3 * (5 + C), generator=g) * 2).to(DEV) for s in (8, 4, 2)]
+    imgs = torch.zeros(B, 64, 64, 3, dtype=torch.uint8, device=DEV)
+    det = U.bbox_nms(heads, 64, num_classes=C)
+    outs = U.draw_bbox(imgs, heads, 64, C)
+    assert len(outs) == B and int(det[3].sum()) > 0
+    for b in range(B):
+        want = IM.draw_boxes(np.zeros((64, 64, 3), np.uint8), det[0][b].cpu().numpy(), det[2][b].cpu().numpy(),
+                             int(det[3][b]), C, int(0.6 * 128 / 600))
+        np.testing.assert_array_equal(outs[b].cpu().numpy(), want)

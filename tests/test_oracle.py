@@ -407,3 +407,47 @@ def test_label_assignment_known_answers():
     bx, scale, px, py = LB.letterbox_boxes(np.array([[10., 20., 110., 120., 0.]]), 200, 400, 416)
     assert abs(scale - 1.04) < 1e-12 and (px, py) == (0, 104)
     np.testing.assert_allclose(bx[0, :4], [10.4, 124.8, 114.4, 228.8])
+
+
+# ---- image utilities (utils.py:5-31, 197-242) -----------------------------------------------------
+def test_letterbox_known_answers():
+    from oracle import image_np as IM
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (4, 4, 3)).astype(np.uint8)
+    np.testing.assert_array_equal(IM.letterbox(img, 4), img.astype(np.float32) / 256)      # same size: untouched
+    # 2 -> 4 along one axis: the weights of half-pixel-centre bilinear resize with replicated edges
+    a, b = 10.0, 50.0
+    line = np.array([[[a] * 3, [b] * 3]] * 2, np.float32)                               # [2,2,3], constant down the rows
+    out = IM.resize_linear(line, 4, 4)
+    np.testing.assert_allclose(out[0, :, 0], [a, 0.75 * a + 0.25 * b, 0.25 * a + 0.75 * b, b])
+    assert np.ptp(out[:, 1, 0]) == 0
+    # a 2 x 4 image in a 4 x 4 square: scale 1, one padding row above and below, value 128 / 256
+    wide = rng.integers(0, 256, (2, 4, 3)).astype(np.uint8)
+    o = IM.letterbox(wide, 4)
+    np.testing.assert_array_equal(o[1:3], wide.astype(np.float32) / 256)
+    assert (o[0] == 0.5).all() and (o[3] == 0.5).all()
+    # the reference's argument order: the resized image has new_width rows and new_height columns
+    q = IM.letterbox(wide, 4, literal=True)
+    assert (q[:, 0] == 0.5).all() and (q[:, 3] == 0.5).all() and not (q[:, 1:3] == 0.5).all()
+    np.testing.assert_array_equal(q[:, 1:3], IM.resize_linear(wide, 4, 2) / np.float32(256))
+    # square images do not see the difference
+    sq = rng.integers(0, 256, (6, 6, 3)).astype(np.uint8)
+    np.testing.assert_array_equal(IM.letterbox(sq, 8), IM.letterbox(sq, 8, literal=True))
+
+
+def test_draw_boxes_known_answer():
+    from oracle import image_np as IM
+    img = np.zeros((8, 8, 3), np.uint8)
+    boxes = np.array([[0.25, 0.25, 0.75, 0.75], [0.0, 0.0, 0.5, 0.5]], np.float32)
+    out = IM.draw_boxes(img, boxes, np.array([0.0, 2.0]), 1, 4, 1)
+    ring = np.zeros((8, 8), bool)
+    ring[2, 2:7] = ring[6, 2:7] = ring[2:7, 2] = ring[2:7, 6] = True
+    assert ring.sum() == 16
+    assert (out[ring] == [255, 0, 0]).all() and (out[~ring] == 0).all()                  # class 0 of 4: hue 0 = red
+    two = IM.draw_boxes(img, boxes, np.array([0.0, 2.0]), 2, 4, 1)
+    assert (two[4, 2] == [0, 255, 255]).all() and (two[2, 4] == [0, 255, 255]).all()    # the later box paints over the earlier
+    assert (two[6, 6] == [255, 0, 0]).all()
+    skipped = IM.draw_boxes(img, boxes, np.array([7.0, -1.0]), 2, 4, 1)
+    assert (skipped == 0).all()                                                         # classes outside [0, C) are not drawn
+    thick = IM.draw_boxes(img, boxes[:1], np.array([1.0]), 1, 4, 3)
+    assert (thick[1:4, 1:8] != 0).any(axis=-1).all() and (thick[4, 4] == 0).all()

@@ -434,6 +434,23 @@ int ymx_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dtype
     return launch_spp_concat(x, y, B, H, W, C, dtype, (hipStream_t)stream);
 }
 
+int ymx_letterbox(const void *images, int in_dtype, int B, int H, int W, void *out, int out_dtype, int target, int literal,
+                  void *stream) {
+    if (!images || !out) return fail(YMX_EARG, "letterbox: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || target <= 0) return fail(YMX_EARG, "letterbox: non-positive size");
+    if (in_dtype != YMX_F32 && in_dtype != YMX_U8) return fail(YMX_EARG, "letterbox: source dtype %d (fp32 or 8-bit)", in_dtype);
+    if (out_dtype != YMX_F32 && out_dtype != YMX_BF16) return fail(YMX_EARG, "letterbox: output dtype %d", out_dtype);
+    if ((size_t)B * H * W >= ((size_t)1 << 40) || (size_t)B * target * target >= ((size_t)1 << 40)) return fail(YMX_EUNSUPPORTED, "letterbox: too many pixels");
+    return launch_letterbox(images, in_dtype == YMX_U8, B, H, W, out, out_dtype == YMX_BF16, target, literal != 0, (hipStream_t)stream);
+}
+
+int ymx_draw_boxes(unsigned char *images, int B, int H, int W, const float *boxes, const float *classes, const int *valid,
+                   int max_boxes, const unsigned char *colors, int C, int thickness, void *stream) {
+    if (!images || !boxes || !classes || !valid || !colors) return fail(YMX_EARG, "draw_boxes: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || max_boxes <= 0 || C <= 0) return fail(YMX_EARG, "draw_boxes: non-positive size");
+    return launch_draw_boxes(images, B, H, W, boxes, classes, valid, max_boxes, colors, C, thickness, (hipStream_t)stream);
+}
+
 size_t ymx_yolo_loss_workspace_bytes(int B, int S) { return yolo_loss_workspace_bytes(B, S); }
 
 int ymx_yolo_loss(const float *conv, int conv_ld, const float *pred, const float *label, long long label_stride,

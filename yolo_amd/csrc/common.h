@@ -223,6 +223,9 @@ int launch_affine_act(const void *x, const float *scale, const float *shift, voi
 int launch_bbox_iou(const float *b1, const float *b2, float *out, long long n, int giou,
                     hipStream_t s);
 int launch_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dtype, hipStream_t s);
+int launch_letterbox(const void *src, int in_u8, int B, int H, int W, void *dst, int out_bf16, int T, int literal, hipStream_t s);
+int launch_draw_boxes(unsigned char *img, int B, int H, int W, const float *boxes, const float *classes, const int *valid, int M,
+                      const unsigned char *colors, int C, int thick, hipStream_t s);
 size_t yolo_loss_workspace_bytes(int B, int S);
 int launch_yolo_loss(const float *conv, int conv_ld, const float *pred, const float *label, long long label_stride,
                      const float *bboxes, long long bbox_stride, int B, int S, int C, int NB, float stride, float xyscale, const float *anchors, float iou_thr, float *out,

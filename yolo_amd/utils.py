@@ -1,8 +1,9 @@
 """Head post-processing and box maths, same names and signatures as the reference's utils.py.
 
-Mirrors /root/reference/utils.py:33-194.  The host-only helpers of that file
-(image_preprocess, draw_bbox: OpenCV on numpy arrays) are not part of the GPU path and
-are not provided.  All device work goes through libymx; tensors must be on a GPU.
+Mirrors /root/reference/utils.py:5-242.  image_preprocess and draw_bbox, OpenCV on numpy
+arrays in the reference, take GPU tensors here (letterbox resize and box outlines are
+kernels of libymx; text labels are not rendered).  All device work goes through libymx;
+tensors must be on a GPU.
 
 Layout note: score matrices produced here are stored class-major ([B,C,N] in memory)
 because the NMS kernel streams one class row at a time; they are returned as [B,N,C]
@@ -319,3 +320,79 @@ def bbox_iou(bboxes1, bboxes2):
 def bbox_giou(bboxes1, bboxes2):
     """Generalised IoU of (cx,cy,w,h) boxes (utils.py:65-105)."""
     return _iou_call(bboxes1, bboxes2, True)
+
+
+def image_preprocess(image, bboxes, train_input_size, literal=False, dtype=torch.float32):
+    """Letterbox resize of an image (or a batch of equally sized images) and of its boxes
+    (utils.py:5-31).
+
+    image [H,W,3] or [B,H,W,3], uint8 or float32, on the GPU; bboxes [n, >=4] (xmin, ymin,
+    xmax, ymax, ...) numpy array or None.  Returns (image [T,T,3] or [B,T,T,3] in ``dtype``
+    = value / 256 with 128-filled borders, boxes scaled and shifted as utils.py:29-30).
+    literal=True keeps the reference's cv2.resize argument order (utils.py:21), which swaps
+    the resized height and width of a non-square image; the default resizes to
+    (new_height rows, new_width columns), what the box arithmetic assumes."""
+    _lib.require_gpu(image)
+    single = image.dim() == 3
+    x = image.unsqueeze(0) if single else image
+    if x.dim() != 4 or x.shape[-1] != 3:
+        raise ValueError("image: expected [H,W,3] or [B,H,W,3], got %s" % (tuple(image.shape),))
+    if x.dtype not in (torch.uint8, torch.float32):
+        raise ValueError("image must be uint8 or float32")
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("output dtype must be float32 or bfloat16")
+    x = x.contiguous()
+    B, H, W = x.shape[0], x.shape[1], x.shape[2]
+    T = int(train_input_size)
+    out = torch.empty((B, T, T, 3), device=x.device, dtype=dtype)
+    _lib.launch("ymx_letterbox", x, _lib.ptr(x), 2 if x.dtype == torch.uint8 else 0, B, H, W, _lib.ptr(out),
+                _lib.dtype_code(dtype), T, 1 if literal else 0)
+    boxes = None
+    if bboxes is not None:
+        scale = min(T / W, T / H)
+        new_h, new_w = int(scale * H), int(scale * W)
+        pad_h, pad_w = (T - new_h) // 2, (T - new_w) // 2
+        boxes = np.array(bboxes, np.float64, copy=True)
+        boxes[:, [0, 2]] = boxes[:, [0, 2]] * scale + pad_w
+        boxes[:, [1, 3]] = boxes[:, [1, 3]] * scale + pad_h
+    return (out[0] if single else out), boxes
+
+
+def class_colors(num_classes):
+    """The colour table of draw_bbox (utils.py:211-213): hue = class / num_classes at full
+    saturation and value, as 8-bit RGB, [num_classes, 3] uint8."""
+    import colorsys
+    cols = [colorsys.hsv_to_rgb(1.0 * c / num_classes, 1.0, 1.0) for c in range(num_classes)]
+    return np.array([[int(r * 255), int(g * 255), int(b * 255)] for r, g, b in cols], np.uint8)
+
+
+def draw_boxes(images, boxes, classes, valid_detections, num_classes, thickness=None):
+    """Outlines detections on a batch of images in place (the cv2.rectangle calls of
+    utils.py:216-231).  images [B,H,W,3] uint8 on the GPU, the other arguments as
+    bbox_nms returns them.  thickness None = int(0.6 * (H + W) / 600), at least 1."""
+    _lib.require_gpu(images, boxes, classes, valid_detections)
+    if images.dim() != 4 or images.shape[-1] != 3 or images.dtype != torch.uint8 or not images.is_contiguous():
+        raise ValueError("images: expected contiguous uint8 [B,H,W,3]")
+    B, H, W = images.shape[0], images.shape[1], images.shape[2]
+    bx = boxes.float().contiguous()
+    cl = classes.float().contiguous()
+    vd = valid_detections.to(torch.int32).contiguous()
+    if bx.dim() != 3 or bx.shape[0] != B or bx.shape[2] != 4 or cl.shape != bx.shape[:2] or vd.shape != (B,):
+        raise ValueError("boxes [B,M,4], classes [B,M] and valid_detections [B] are required")
+    if thickness is None:
+        thickness = int(0.6 * (H + W) / 600)
+    colors = torch.from_numpy(class_colors(num_classes)).to(images.device)
+    _lib.launch("ymx_draw_boxes", images, _lib.ptr(images), B, H, W, _lib.ptr(bx), _lib.ptr(cl), _lib.ptr(vd),
+                bx.shape[1], _lib.ptr(colors), int(num_classes), max(int(thickness), 1))
+    return images
+
+
+def draw_bbox(images, model_output, image_size, num_classes, classes=None, show_label=True):
+    """NMS on the model output, then every detection outlined on its image (utils.py:197-242).
+
+    images [B,H,W,3] uint8 on the GPU (drawn on in place, as the reference draws on its
+    arrays); returns the list of the B images.  Class-name labels (``classes``,
+    ``show_label``: cv2.putText in the reference) are not rendered."""
+    det = bbox_nms(model_output, image_size, num_classes=num_classes)
+    draw_boxes(images, det[0], det[2], det[3], num_classes)
+    return [images[i] for i in range(images.shape[0])]
