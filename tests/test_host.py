@@ -288,3 +288,118 @@ def test_options_are_per_thread():
     t = threading.Thread(target=disable)
     t.start(); t.join()
     assert seen[-1] == "igemm" and _label(_conv_op(*op_args)) == "halo"
+
+
+# ---- TFRecord shards (dataset.py:56-126) ------------------------------------------------------------
+def _example_classes():
+    """tf.train.Example / Features / Feature and TensorProto built from their published .proto
+    definitions with the protobuf runtime (an encoder independent of yolo_amd.tfrecord)."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    F = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto(name="ymx_example_test.proto", package="ymxt", syntax="proto3")
+
+    def msg(name, fields, nested=()):
+        m = fd.message_type.add(name=name)
+        for fname, num, typ, label, tname, oneof in fields:
+            f = m.field.add(name=fname, number=num, type=typ, label=label)
+            if tname:
+                f.type_name = tname
+            if oneof is not None:
+                f.oneof_index = oneof
+        return m
+
+    O, R = F.LABEL_OPTIONAL, F.LABEL_REPEATED
+    msg("BytesList", [("value", 1, F.TYPE_BYTES, R, None, None)])
+    msg("FloatList", [("value", 1, F.TYPE_FLOAT, R, None, None)])
+    msg("Int64List", [("value", 1, F.TYPE_INT64, R, None, None)])
+    m = msg("Feature", [("bytes_list", 1, F.TYPE_MESSAGE, O, ".ymxt.BytesList", 0), ("float_list", 2, F.TYPE_MESSAGE, O, ".ymxt.FloatList", 0),
+                        ("int64_list", 3, F.TYPE_MESSAGE, O, ".ymxt.Int64List", 0)])
+    m.oneof_decl.add(name="kind")
+    m = msg("Features", [("feature", 1, F.TYPE_MESSAGE, R, ".ymxt.Features.FeatureEntry", None)])
+    e = m.nested_type.add(name="FeatureEntry")
+    e.field.add(name="key", number=1, type=F.TYPE_STRING, label=O)
+    e.field.add(name="value", number=2, type=F.TYPE_MESSAGE, label=O, type_name=".ymxt.Feature")
+    e.options.map_entry = True
+    msg("Example", [("features", 1, F.TYPE_MESSAGE, O, ".ymxt.Features", None)])
+    msg("Dim", [("size", 1, F.TYPE_INT64, O, None, None), ("name", 2, F.TYPE_STRING, O, None, None)])
+    msg("TensorShapeProto", [("dim", 2, F.TYPE_MESSAGE, R, ".ymxt.Dim", None), ("unknown_rank", 3, F.TYPE_BOOL, O, None, None)])
+    msg("TensorProto", [("dtype", 1, F.TYPE_INT32, O, None, None), ("tensor_shape", 2, F.TYPE_MESSAGE, O, ".ymxt.TensorShapeProto", None),
+                        ("version_number", 3, F.TYPE_INT32, O, None, None), ("tensor_content", 4, F.TYPE_BYTES, O, None, None)])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName("ymxt." + n))
+    return get("Example"), get("TensorProto")
+
+
+def test_tfrecord_format():
+    from yolo_amd import tfrecord as T
+    # CRC-32C check values of RFC 3720 B.4 and the common "123456789" vector
+    assert T.crc32c(b"123456789") == 0xE3069283
+    assert T.crc32c(bytes(32)) == 0x8A9136AA
+    assert T.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert T.crc32c(bytes(range(32))) == 0x46DD794E
+    assert T.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
+    c = T.crc32c(b"abc")
+    assert T.masked_crc32c(b"abc") == (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+    # wire encoding by hand: Example{features{feature{"a": float_list [1.0]}}}
+    assert T.example({"a": T.floats_feature([1.0])}) == bytes.fromhex("0a0f0a0d0a0161120812060a040000803f")
+    # ... and against the protobuf runtime on the messages' published definitions
+    Example, TensorProto = _example_classes()
+    rng = np.random.default_rng(0)
+    img = rng.random((4, 4, 3)).astype(np.float16)
+    tp = TensorProto(dtype=19, tensor_content=img.tobytes())
+    for d in img.shape:
+        tp.tensor_shape.dim.add(size=d)
+    assert T.serialize_tensor(img) == tp.SerializeToString(deterministic=True)
+    np.testing.assert_array_equal(T.parse_tensor(T.serialize_tensor(img)), img)
+    for arr in (np.arange(6, dtype=np.int64).reshape(2, 3), np.float32(3.5), np.zeros((0, 2), np.float32), np.arange(5, dtype=np.uint8)):
+        back = T.parse_tensor(T.serialize_tensor(arr))
+        assert back.dtype == arr.dtype and back.shape == np.shape(arr) and (back == arr).all()
+    vals = rng.random(7).astype(np.float16)
+    ex = Example()
+    ex.features.feature["image"].bytes_list.value.append(T.serialize_tensor(img))
+    ex.features.feature["small_targets"].float_list.value.extend([float(v) for v in vals])
+    ex.features.feature["count"].int64_list.value.extend([3, -1, 1 << 40])
+    mine = T.example({"small_targets": T.floats_feature(vals), "image": T.bytes_feature(T.serialize_tensor(img)),
+                      "count": T.int64_feature([3, -1, 1 << 40])})
+    assert mine == ex.SerializeToString(deterministic=True)
+    parsed = T.parse_example(mine)
+    np.testing.assert_array_equal(parsed["small_targets"], vals.astype(np.float32))
+    np.testing.assert_array_equal(parsed["count"], [3, -1, 1 << 40])
+    np.testing.assert_array_equal(T.parse_tensor(parsed["image"]), img)
+
+
+def test_to_tfrecord_shards(tmp_path):
+    from yolo_amd import tfrecord as T
+    rng = np.random.default_rng(1)
+    examples = []
+    for _ in range(7):
+        image = rng.random((1, 8, 8, 3)).astype(np.float16)
+        targets = tuple((rng.random((1, n)) * (rng.random((1, n)) < 0.2)).astype(np.float16) for n in (40, 20, 10))
+        examples.append((image, targets))
+    paths = T.to_tfrecord(examples, str(tmp_path / "train.tfrecord"), 3)
+    assert [os.path.basename(p) for p in paths] == ["train.tfrecord.shard%dof3" % k for k in (1, 2, 3)]
+    seen = 0
+    for p in paths:
+        recs = list(T.read_records(p))
+        assert len(recs) == 2                                   # 7 // 3 per shard, the seventh example is dropped
+        for r in recs:
+            image, targets = examples[seen]
+            f = T.parse_example(r)
+            np.testing.assert_array_equal(T.parse_tensor(f["image"]), image[0])
+            for key, t in zip(("small_targets", "medium_targets", "large_targets"), targets):
+                np.testing.assert_array_equal(f[key], t[0].astype(np.float32))
+            seen += 1
+    # a flipped byte is caught by the checksums
+    raw = bytearray(open(paths[0], "rb").read())
+    raw[20] ^= 1
+    bad = tmp_path / "bad"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(ValueError):
+        list(T.read_records(str(bad)))
+    # sparse form: the indices of the non-zero targets, as the reference stores them
+    sp = T.to_tfrecord(examples[:2], str(tmp_path / "sp"), 1, use_sparse=True)
+    f = T.parse_example(next(T.read_records(sp[0])))
+    np.testing.assert_array_equal(T.parse_tensor(f["small_targets"]), np.argwhere(examples[0][1][0][0] != 0))
+    with pytest.raises(ValueError):
+        T.to_tfrecord(examples[:2], str(tmp_path / "x"), 3)

@@ -8,12 +8,13 @@ declared in include/ymx.h.  There is no CPU fallback.
 from .config import config
 from .utils import *          # noqa: F401,F403
 from .utils import (decode, decode_train, decode_predict, filter_bboxes, bbox_nms, bbox_iou, bbox_giou,
-                    combined_non_max_suppression)
+                    combined_non_max_suppression, image_preprocess, draw_bbox, draw_boxes)
 from . import layers
 from . import backbones
 from . import detectors
 from . import losses
 from . import dataset
+from . import tfrecord
 from . import engine
 from . import dist
 from .engine import Detector

@@ -1,11 +1,11 @@
 """Training-target construction, after the reference's dataset.py / utils.image_preprocess.
 
-Of /root/reference/dataset.py only the part that feeds the loss is provided:
-``preprocess_true_boxes`` (dataset.py:387-482), batched and on the GPU, and the target
-packing of dataset.py:210-218.  The WIDER-face index parser, the OpenCV augmentations and
-the TFRecord writer are host-side file and image utilities outside the GPU path and are not
-provided; of ``utils.image_preprocess`` (utils.py:5-31) only the box arithmetic is (the
-image resize there is cv2's).
+Of /root/reference/dataset.py the parts that feed the loss are provided:
+``preprocess_true_boxes`` (dataset.py:387-482), batched and on the GPU, the target packing
+of dataset.py:210-218 and the TFRecord shard writer of dataset.py:64-126 (``to_tfrecord``,
+host-side, in yolo_amd/tfrecord.py).  The WIDER-face index parser and the OpenCV
+augmentations are not provided.  ``utils.image_preprocess`` (utils.py:5-31) lives in
+yolo_amd/utils.py as in the reference; ``letterbox_boxes`` here is its box arithmetic alone.
 """
 import ctypes
 
@@ -14,6 +14,7 @@ import torch
 
 from . import _lib
 from .config import config as _config
+from .tfrecord import to_tfrecord            # noqa: F401  (dataset.py:64-126)
 
 _YOLO = _config["yolo"]
 MAX_BBOX_PER_SCALE = 128       # dataset.py:9
