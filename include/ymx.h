@@ -278,6 +278,19 @@ int ymx_yolo_loss(const float *conv, int conv_ld, const float *pred, const float
                   const float *anchors /* host */, float iou_loss_threshold, float *out,
                   float *per_image, void *workspace, size_t ws_bytes, void *stream);
 
+/* ---- YOLO loss of one scale, gradient ------------------------------------------
+ * d(w0 * giou_loss + w1 * conf_loss + w2 * prob_loss) / d conv for the loss ymx_yolo_loss
+ * computes with pred = NULL (decode inside), i.e. what back-propagation hands to the head's
+ * output convolution in a training step (losses.py:10-66 differentiated; the background
+ * mask of losses.py:30 is a comparison and carries no gradient).  Same arguments as
+ * ymx_yolo_loss; term_weights device [3] (NULL = all 1), dconv [B,S,S,3,5+C] fp32 dense,
+ * fully written (zero where no term depends on the value).  No workspace, deterministic. */
+int ymx_yolo_loss_grad(const float *conv, int conv_ld, const float *label, long long label_stride,
+                       const float *bboxes, long long bbox_stride, int B, int S, int C, int n_boxes,
+                       float stride, float xyscale, const float *anchors /* host */,
+                       float iou_loss_threshold, const float *term_weights /* device */,
+                       float *dconv, void *stream);
+
 /* ---- letterbox resize ---------------------------------------------------------
  * Replaces the image half of image_preprocess (utils.py:16-26): the image is resized by
  * scale = min(target/W, target/H) (bilinear, half-pixel centres, edges replicated: the

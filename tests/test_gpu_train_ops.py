@@ -244,3 +244,43 @@ def test_draw_bbox_end_to_end():
         want = IM.draw_boxes(np.zeros((64, 64, 3), np.uint8), det[0][b].cpu().numpy(), det[2][b].cpu().numpy(),
                              int(det[3][b]), C, int(0.6 * 128 / 600))
         np.testing.assert_array_equal(outs[b].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("S,C,scale,B", [(13, 80, 2, 3), (26, 80, 1, 2), (52, 3, 0, 2), (7, 1, 1, 2)])
+def test_yolo_loss_gradient_vs_autograd_oracle(S, C, scale, B):
+    """d loss / d head output from the fused kernel (through torch.autograd) against the
+    automatic gradient of the torch restatement, fp32 tolerance 1e-3 of the gradient's scale
+    per tensor and 2e-3 element by element on the responsible rows; per-term upstream weights."""
+    import yolo_amd as Y
+    from yolo_amd import losses as L
+    from oracle import loss_torch as LT
+    cfg = Y.config
+    conv, label, bboxes = loss_case(B, S, C, scale, seed=300 + S + C, n_gt=6)
+    target = np.concatenate([label.reshape(B, -1), bboxes.reshape(B, -1)], axis=1)
+    out = conv.reshape(B, S, S, -1)
+    t_d = torch.from_numpy(target).to(DEV)
+    for weights in ((1.0, 1.0, 1.0), (0.5, 2.0, 3.0)):
+        o_d = torch.from_numpy(out).to(DEV).requires_grad_(True)
+        terms = L.loss_at_scale(t_d, o_d, scale, C, cfg["strides"], 0.5, cfg["xyscale"], cfg["anchors"], terms=True)
+        (terms * torch.tensor(weights, device=DEV)).sum().backward()
+        (g, c, p), want = LT.loss_and_grad(target, out, scale, C, P.STRIDES, 0.5, P.XYSCALE, P.ANCHORS, weights)
+        np.testing.assert_allclose(terms.detach().cpu().numpy().astype(np.float64), [g, c, p], rtol=1e-3)
+        got = o_d.grad.cpu().numpy().astype(np.float64)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max()
+        D = 5 + C
+        rows = label[..., 4].reshape(B, -1) > 0
+        gr, wr = got.reshape(B, -1, D)[rows], want.reshape(B, -1, D)[rows]
+        assert rows.sum() > 0 and np.abs(gr - wr).max() <= 2e-3 * np.abs(wr).max()
+        # nothing depends on the class and box logits of rows that are not responsible
+        assert (got.reshape(B, -1, D)[~rows][:, [0, 1, 2, 3] + list(range(5, D))] == 0).all()
+    # the summed closure is differentiable too, and the gradient is reproducible bit for bit
+    fs = L.get_yolo_loss_at_scales([0, 1, 2], C, cfg["strides"], 0.5, cfg["xyscale"], cfg["anchors"])
+    grads = []
+    for _ in range(2):
+        o_d = torch.from_numpy(out).to(DEV).requires_grad_(True)
+        fs[2 - scale](t_d, o_d).backward()
+        grads.append(o_d.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    (g, c, p), want = LT.loss_and_grad(target, out, scale, C, P.STRIDES, 0.5, P.XYSCALE, P.ANCHORS)
+    assert np.abs(grads[0].cpu().numpy() - want).max() <= 1e-3 * np.abs(want).max()

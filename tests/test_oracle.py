@@ -451,3 +451,34 @@ def test_draw_boxes_known_answer():
     assert (skipped == 0).all()                                                         # classes outside [0, C) are not drawn
     thick = IM.draw_boxes(img, boxes[:1], np.array([1.0]), 1, 4, 3)
     assert (thick[1:4, 1:8] != 0).any(axis=-1).all() and (thick[4, 4] == 0).all()
+
+
+def test_loss_torch_restatement_matches_numpy_and_finite_differences():
+    """The torch restatement used for gradients gives the numpy restatement's loss values, and
+    its automatic gradient agrees with central finite differences of its own forward."""
+    from oracle import loss_torch as LT
+    from oracle import loss_np as LN
+    from tests_support import loss_case
+    B, S, C, scale = 2, 7, 3, 1
+    conv, label, bboxes = loss_case(B, S, C, scale, seed=21, n_gt=5)
+    target = np.concatenate([label.reshape(B, -1), bboxes.reshape(B, -1)], axis=1)
+    out = conv.reshape(B, S, S, -1)
+    (g, c, p), grad = LT.loss_and_grad(target, out, scale, C, P.STRIDES, 0.5, P.XYSCALE, P.ANCHORS)
+    want = LN.loss_at_scale(target, out, scale, C, P.STRIDES, 0.5, P.XYSCALE, P.ANCHORS)[1]
+    np.testing.assert_allclose([g, c, p], np.array(want, np.float64), rtol=2e-5)
+    assert grad.shape == out.shape and np.isfinite(grad).all() and np.abs(grad).max() > 0
+    rng = np.random.default_rng(0)
+    flat = out.astype(np.float64).reshape(-1)
+    resp = np.argwhere(label[..., 4].reshape(-1) > 0).reshape(-1)
+    D = 5 + C
+    picks = list(rng.integers(0, flat.size, 12)) + [int(resp[0]) * D + k for k in range(D)]
+    for i in picks:
+        h = 1e-5
+        vals = []
+        for sgn in (1, -1):
+            pert = flat.copy()
+            pert[i] += sgn * h
+            (g2, c2, p2), _ = LT.loss_and_grad(target, pert.reshape(out.shape), scale, C, P.STRIDES, 0.5, P.XYSCALE, P.ANCHORS)
+            vals.append(g2 + c2 + p2)
+        fd = (vals[0] - vals[1]) / (2 * h)
+        assert abs(fd - grad.reshape(-1)[i]) <= 1e-5 + 1e-4 * abs(fd), (i, fd, grad.reshape(-1)[i])

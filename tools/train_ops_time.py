@@ -63,6 +63,16 @@ def main():
         alg = 2 * B * S * S * 3 * (5 + C) * 4 + B * 128 * 4 * 4
         print("yolo_loss  S=%d B=%d: %.3f ms, %.1f MB algorithmic -> %.0f GB/s = %.3f of 8 TB/s" %
               (S, B, ms, alg / 1e6, alg / ms / 1e6, alg / ms / 1e6 / PEAK))
+        og = out.clone().requires_grad_(True)
+        w3 = torch.ones(3, device=DEV)
+
+        def fb():
+            og.grad = None
+            (L.loss_at_scale(tg[scale], og, scale, C, cfg["strides"], 0.5, cfg["xyscale"], cfg["anchors"], terms=True) * w3).sum().backward()
+        ms2 = timed(fb)
+        algb = alg + B * S * S * 3 * (5 + C) * 4
+        print("yolo_loss forward + gradient S=%d: %.3f ms (gradient part %.3f ms, %.1f MB algorithmic incl. the gradient written -> %.3f of 8 TB/s)" %
+              (S, ms2, ms2 - ms, algb / 1e6, algb / max(ms2 - ms, 1e-6) / 1e6 / PEAK))
     for H, Cc, dt in ((13, 512, torch.bfloat16), (19, 512, torch.bfloat16), (13, 512, torch.float32)):
         x = torch.randn(B, H, H, Cc, device=DEV).to(dt)
         ms = timed(lambda: spp_concat(x))

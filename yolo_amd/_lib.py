@@ -57,6 +57,8 @@ SIGNATURES = {
                               _vp, _sz, _vp]),
     "ymx_nms_combined_static": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ymx_spp_concat": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ymx_yolo_loss_grad": (_i, [_vp, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _i, _i, _i, _i, _f, _f, ctypes.POINTER(_f), _f,
+                                _vp, _vp, _vp]),
     "ymx_letterbox": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "ymx_draw_boxes": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "ymx_yolo_loss_workspace_bytes": (_sz, [_i, _i]),

@@ -434,6 +434,20 @@ int ymx_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dtype
     return launch_spp_concat(x, y, B, H, W, C, dtype, (hipStream_t)stream);
 }
 
+int ymx_yolo_loss_grad(const float *conv, int conv_ld, const float *label, long long label_stride, const float *bboxes,
+                       long long bbox_stride, int B, int S, int C, int n_boxes, float stride, float xyscale, const float *anchors,
+                       float iou_loss_threshold, const float *term_weights, float *dconv, void *stream) {
+    if (!conv || !label || !bboxes || !anchors || !dconv) return fail(YMX_EARG, "yolo_loss_grad: null pointer");
+    if (B <= 0 || S <= 0 || C <= 0 || n_boxes <= 0) return fail(YMX_EARG, "yolo_loss_grad: non-positive size");
+    if (B > 65535) return fail(YMX_EUNSUPPORTED, "yolo_loss_grad: batch above 65535");
+    if (conv_ld != 0 && conv_ld < 3 * (5 + C)) return fail(YMX_EARG, "yolo_loss_grad: cell stride %d below 3*(5+C) = %d", conv_ld, 3 * (5 + C));
+    if (label_stride != 0 && label_stride < (long long)3 * S * S * (5 + C)) return fail(YMX_EARG, "yolo_loss_grad: label image stride below one image");
+    if (bbox_stride != 0 && bbox_stride < (long long)4 * n_boxes) return fail(YMX_EARG, "yolo_loss_grad: box image stride below one image");
+    if ((((uintptr_t)conv) | ((uintptr_t)label) | ((uintptr_t)bboxes) | ((uintptr_t)dconv)) & 3) return fail(YMX_EARG, "yolo_loss_grad: pointers must be 4-byte aligned");
+    return launch_yolo_loss_grad(conv, conv_ld, label, label_stride, bboxes, bbox_stride, B, S, C, n_boxes, stride, xyscale, anchors,
+                                 iou_loss_threshold, term_weights, dconv, (hipStream_t)stream);
+}
+
 int ymx_letterbox(const void *images, int in_dtype, int B, int H, int W, void *out, int out_dtype, int target, int literal,
                   void *stream) {
     if (!images || !out) return fail(YMX_EARG, "letterbox: null pointer");

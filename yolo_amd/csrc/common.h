@@ -227,6 +227,9 @@ int launch_letterbox(const void *src, int in_u8, int B, int H, int W, void *dst,
 int launch_draw_boxes(unsigned char *img, int B, int H, int W, const float *boxes, const float *classes, const int *valid, int M,
                       const unsigned char *colors, int C, int thick, hipStream_t s);
 size_t yolo_loss_workspace_bytes(int B, int S);
+int launch_yolo_loss_grad(const float *conv, int conv_ld, const float *label, long long label_stride, const float *bboxes,
+                          long long bbox_stride, int B, int S, int C, int NB, float stride, float xyscale, const float *anchors,
+                          float iou_thr, const float *weights, float *dconv, hipStream_t s);
 int launch_yolo_loss(const float *conv, int conv_ld, const float *pred, const float *label, long long label_stride,
                      const float *bboxes, long long bbox_stride, int B, int S, int C, int NB, float stride, float xyscale, const float *anchors, float iou_thr, float *out,
                      float *per_image, void *workspace, hipStream_t s);

@@ -326,6 +326,210 @@ int launch_yolo_loss(const float *conv, int conv_ld, const float *pred, const fl
 }
 
 
+// ---- YOLO loss of one scale, gradient with respect to the raw head map ------------------------
+// Value and its four partial derivatives with respect to the predicted box (cx, cy, w, h):
+// forward-mode differentiation of the GIoU expression of /root/reference/utils.py:65-105,
+// so that the gradient follows that text operation by operation.  A min / max passes the
+// derivative of the operand it selects (the first one on a tie, as TensorFlow's gradient
+// does); divide_no_nan is 0 with zero derivative where the divisor is 0.
+struct Dual4 {
+    float v, d[4];
+};
+__device__ __forceinline__ Dual4 dconst(float v) { return Dual4{v, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ Dual4 dvar(float v, int k) {
+    Dual4 r = dconst(v);
+    r.d[k] = 1.0f;
+    return r;
+}
+__device__ __forceinline__ Dual4 operator+(const Dual4 &a, const Dual4 &b) {
+    return Dual4{a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2], a.d[3] + b.d[3]}};
+}
+__device__ __forceinline__ Dual4 operator-(const Dual4 &a, const Dual4 &b) {
+    return Dual4{a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2], a.d[3] - b.d[3]}};
+}
+__device__ __forceinline__ Dual4 operator*(const Dual4 &a, const Dual4 &b) {
+    return Dual4{a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2],
+                             a.d[3] * b.v + a.v * b.d[3]}};
+}
+__device__ __forceinline__ Dual4 operator*(const Dual4 &a, float s) {
+    return Dual4{a.v * s, {a.d[0] * s, a.d[1] * s, a.d[2] * s, a.d[3] * s}};
+}
+__device__ __forceinline__ Dual4 dmax(const Dual4 &a, const Dual4 &b) { return a.v >= b.v ? a : b; }
+__device__ __forceinline__ Dual4 dmin(const Dual4 &a, const Dual4 &b) { return a.v <= b.v ? a : b; }
+__device__ __forceinline__ Dual4 ddiv_no_nan(const Dual4 &a, const Dual4 &b) {
+    if (b.v == 0.0f) return dconst(0.0f);
+    const float inv = 1.0f / b.v, q = a.v * inv;
+    return Dual4{q, {(a.d[0] - q * b.d[0]) * inv, (a.d[1] - q * b.d[1]) * inv, (a.d[2] - q * b.d[2]) * inv,
+                     (a.d[3] - q * b.d[3]) * inv}};
+}
+
+__device__ __forceinline__ Dual4 giou_dual(float px, float py, float pw, float ph, float lx, float ly, float lw, float lh) {
+    const Dual4 X = dvar(px, 0), Y = dvar(py, 1), W = dvar(pw, 2), H = dvar(ph, 3);
+    const Dual4 a1 = W * H, a2 = dconst(lw * lh);
+    const Dual4 x0 = X - W * 0.5f, y0 = Y - H * 0.5f, x1 = X + W * 0.5f, y1 = Y + H * 0.5f;
+    const Dual4 u0 = dconst(lx - lw * 0.5f), v0 = dconst(ly - lh * 0.5f), u1 = dconst(lx + lw * 0.5f), v1 = dconst(ly + lh * 0.5f);
+    const Dual4 iw = dmax(dmin(x1, u1) - dmax(x0, u0), dconst(0.0f));
+    const Dual4 ih = dmax(dmin(y1, v1) - dmax(y0, v0), dconst(0.0f));
+    const Dual4 inter = iw * ih;
+    const Dual4 uni = a1 + a2 - inter;
+    const Dual4 iou = ddiv_no_nan(inter, uni);
+    const Dual4 ew = dmax(x1, u1) - dmin(x0, u0), eh = dmax(y1, v1) - dmin(y0, v0);
+    const Dual4 earea = ew * eh;
+    return iou - ddiv_no_nan(earea - uni, earea);
+}
+
+// Same work split as the forward kernel (one wave per 64 candidates; ground-truth boxes
+// compacted in LDS).  Each lane forms the five leading gradient values of its candidate
+//   d giou_loss / d t_xywh = -respond * scale * d giou / d pred * d pred / d t
+//   d conf_loss / d t_conf = (respond + background) * (2 (p - respond) p (1 - p) bce + (respond - p)^2 (p - respond))
+// (the background mask is a comparison cast to float and carries no gradient), leaves them
+// in LDS, and the wave then writes the 64 x (5+C) block of the gradient with coalesced
+// stores: those five per row, respond * (sigmoid(t) - label) in the class columns of
+// responsible rows, zero everywhere else.  Every value is scaled by the term's weight / B
+// (the loss averages over the batch).
+struct LossGradArgs {
+    LossArgs f;
+    float *dconv;                // [B][S][S][3][5+C] dense
+    const float *w;              // device [3]: upstream gradient of (giou, conf, prob); null = all 1
+};
+
+__global__ void __launch_bounds__(256)
+yolo_loss_grad_kernel(const LossGradArgs g) {
+    const LossArgs &a = g.f;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *sbox = (float *)smem_raw;                 // [NB][4] compacted
+    int *scnt = (int *)(sbox + 4 * a.NB);
+    float *sg = (float *)(scnt + 4);                 // [4 waves][64][5]
+    const int D = 5 + a.C;
+    const int t = threadIdx.x, lane = t & 63;
+    const int q = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int seg = blockIdx.x * 4 + q, b = blockIdx.y;
+    const int Ns = 3 * a.S * a.S;
+    const int c0 = seg * 64;
+    const int cme = c0 + lane, cellm = cme / 3, an = cme - cellm * 3;
+    const bool live = cme < Ns;
+    const float *row = a.conv + ((size_t)b * a.S * a.S + cellm) * a.conv_ld + an * D;
+    const float *lab = a.label + (size_t)b * a.label_stride + (size_t)cme * D;
+    float r[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, l[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { r[i] = row[i]; l[i] = lab[i]; }
+    }
+    if (q == 0) {
+        int n = 0;
+        for (int j0 = 0; j0 < a.NB; j0 += 64) {
+            const int j = j0 + lane;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < a.NB) {
+                const float *p = a.bboxes + (size_t)b * a.bbox_stride + (size_t)j * 4;
+                v = make_float4(p[0], p[1], p[2], p[3]);
+            }
+            const bool nz = (v.x != 0.0f) | (v.y != 0.0f) | (v.z != 0.0f) | (v.w != 0.0f);
+            const unsigned long long m = __ballot(nz);
+            if (nz) *(float4 *)(sbox + 4 * (n + __popcll(m & ((1ull << lane) - 1ull)))) = v;
+            n += __popcll(m);
+        }
+        if (lane == 0) *scnt = n;
+    }
+    __syncthreads();
+    if (seg >= a.nseg) return;
+    const int nbox = *scnt;
+    const float invB = 1.0f / (float)a.B;
+    const float w0 = g.w ? g.w[0] : 1.0f, w1 = g.w ? g.w[1] : 1.0f, w2 = g.w ? g.w[2] : 1.0f;
+
+    const int col = cellm % a.S, rw = cellm / a.S;
+    const float half = 0.5f * (a.xyscale - 1.0f);
+    const float sx = 1.0f / (1.0f + __expf(-r[0])), sy = 1.0f / (1.0f + __expf(-r[1]));
+    const float px = (sx * a.xyscale - half + (float)col) * a.stride;
+    const float py = (sy * a.xyscale - half + (float)rw) * a.stride;
+    const float pw = __expf(r[2]) * a.anchor[an][0];
+    const float ph = __expf(r[3]) * a.anchor[an][1];
+    const float pconf = 1.0f / (1.0f + __expf(-r[4]));
+    const float respond = l[4];
+
+    bool hit = false;
+    {
+        const float area1 = pw * ph;
+        const float ax0 = px - pw * 0.5f, ay0 = py - ph * 0.5f, ax1 = px + pw * 0.5f, ay1 = py + ph * 0.5f;
+        for (int j = 0; j < nbox; ++j) {
+            const float4 gt = *(const float4 *)(sbox + 4 * j);
+            const float bx0 = gt.x - gt.z * 0.5f, by0 = gt.y - gt.w * 0.5f, bx1 = gt.x + gt.z * 0.5f, by1 = gt.y + gt.w * 0.5f;
+            const float iw = fmaxf(fminf(ax1, bx1) - fmaxf(ax0, bx0), 0.0f);
+            const float ih = fmaxf(fminf(ay1, by1) - fmaxf(ay0, by0), 0.0f);
+            const float inter = iw * ih;
+            const float uni = area1 + gt.z * gt.w - inter;
+            hit |= (uni != 0.0f) & !(inter < a.iou_thr * uni);
+        }
+    }
+    float gout[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        if (respond != 0.0f) {
+            const Dual4 gi = giou_dual(px, py, pw, ph, l[0], l[1], l[2], l[3]);
+            const float scale = 2.0f - 1.0f * l[2] * l[3] / (a.input_size * a.input_size);
+            const float k = -respond * scale * w0 * invB;
+            gout[0] = k * gi.d[0] * (sx * (1.0f - sx) * a.xyscale * a.stride);
+            gout[1] = k * gi.d[1] * (sy * (1.0f - sy) * a.xyscale * a.stride);
+            gout[2] = k * gi.d[2] * pw;
+            gout[3] = k * gi.d[3] * ph;
+        }
+        const float mask = respond + (1.0f - respond) * (hit ? 0.0f : 1.0f);
+        const float bce = sce_logits(respond, r[4]);
+        const float d = pconf - respond;
+        gout[4] = w1 * invB * mask * (2.0f * d * pconf * (1.0f - pconf) * bce + d * d * d);
+    }
+    float *mine = sg + q * 320;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) mine[lane * 5 + i] = gout[i];
+    const unsigned long long resp = __ballot(live && respond != 0.0f);
+    // the wave's LDS writes above are read by other lanes of the same wave only
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int nvalid = Ns - c0;
+    nvalid = nvalid > 64 ? 64 : nvalid;
+    float *dst = g.dconv + ((size_t)b * Ns + c0) * D;
+    const float wp = w2 * invB;
+    for (int f = lane; f < nvalid * D; f += 64) {
+        const int rr = f / D, cc = f - rr * D;
+        float v = 0.0f;
+        if (cc < 5) {
+            v = mine[rr * 5 + cc];
+        } else if ((resp >> rr) & 1ull) {
+            const int cw = c0 + rr, cellw = cw / 3, aw = cw - cellw * 3;
+            const float x = a.conv[((size_t)b * a.S * a.S + cellw) * a.conv_ld + aw * D + cc];
+            const float z = a.label[(size_t)b * a.label_stride + (size_t)cw * D + cc];
+            const float rs = a.label[(size_t)b * a.label_stride + (size_t)cw * D + 4];
+            v = wp * rs * (1.0f / (1.0f + __expf(-x)) - z);
+        }
+        dst[f] = v;
+    }
+}
+
+int launch_yolo_loss_grad(const float *conv, int conv_ld, const float *label, long long label_stride, const float *bboxes,
+                          long long bbox_stride, int B, int S, int C, int NB, float stride, float xyscale, const float *anchors,
+                          float iou_thr, const float *weights, float *dconv, hipStream_t s) {
+    LossGradArgs g;
+    LossArgs &a = g.f;
+    a.conv = conv; a.pred = nullptr; a.label = label; a.bboxes = bboxes;
+    a.partial = nullptr;
+    a.B = B; a.S = S; a.C = C; a.NB = NB;
+    a.nseg = (3 * S * S + 63) / 64;
+    a.conv_ld = conv_ld > 0 ? conv_ld : 3 * (5 + C);
+    a.label_stride = label_stride > 0 ? label_stride : (long long)3 * S * S * (5 + C);
+    a.bbox_stride = bbox_stride > 0 ? bbox_stride : (long long)4 * NB;
+    a.stride = stride; a.xyscale = xyscale;
+    for (int i = 0; i < 6; ++i) (&a.anchor[0][0])[i] = anchors[i];
+    a.input_size = (float)S * stride;
+    a.iou_thr = iou_thr;
+    g.dconv = dconv;
+    g.w = weights;
+    const size_t lds = (size_t)NB * 16 + 16 + 4 * 320 * 4;
+    if (lds > 64 * 1024) return fail(YMX_EUNSUPPORTED, "yolo_loss_grad: %d ground-truth slots per image need %zu bytes of LDS", NB, lds);
+    hipLaunchKernelGGL(yolo_loss_grad_kernel, dim3((a.nseg + 3) / 4, B), dim3(256), lds, s, g);
+    return check_launch("yolo_loss_grad");
+}
+
+
 // ---- label assignment ------------------------------------------------------------------------
 // WIDERDataset.preprocess_true_boxes (/root/reference/dataset.py:387-482) for a whole batch, on
 // the device, so that the label tensors (3.6 MB per 416x416 image at 80 classes, nearly all

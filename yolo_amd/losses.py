@@ -3,7 +3,10 @@
 Mirrors /root/reference/losses.py:10-70.  One fused HIP launch per scale (ymx_yolo_loss)
 reads the raw head map, the label tensor and the ground-truth boxes once and produces the
 three loss terms; the [B,S,S,3,128] IoU tensor of losses.py:27 is never materialised.
-Forward only: gradients are not provided.
+The closures are differentiable with respect to the head output: a second fused launch
+(ymx_yolo_loss_grad) produces d loss / d output, wired into torch.autograd, so
+``loss(target, output).backward()`` works on the GPU.  Gradients with respect to the
+targets are not defined (as in the reference, where they are data).
 """
 import ctypes
 
@@ -56,12 +59,7 @@ def yolo_loss(pred, conv, label, bboxes, input_size, iou_loss_threshold):
     return out[0], out[1], out[2]
 
 
-def loss_at_scale(target, output, scale, num_classes, strides, iou_loss_threshold, xyscale, anchors, terms=False):
-    """Body of one closure of get_yolo_loss_at_scales (losses.py:52-66) for ``scale``:
-    target [B, S*S*3*(5+C) + 128*4], output [B,S,S,3*(5+C)] -> giou + conf + prob (0-dim
-    tensor); with terms=True the three terms as a [3] tensor.  The decode of ``output``
-    (decode_train) happens inside the kernel."""
-    _lib.require_gpu(target, output)
+def _split_target(target, output, num_classes):
     if output.dim() != 4 or output.shape[1] != output.shape[2] or output.shape[3] != 3 * (5 + num_classes):
         raise ValueError("output: expected [B,S,S,3*(5+C)], got %s" % (tuple(output.shape),))
     B, S = output.shape[0], output.shape[1]
@@ -69,13 +67,48 @@ def loss_at_scale(target, output, scale, num_classes, strides, iou_loss_threshol
     split = S * S * 3 * D
     if target.dim() != 2 or target.shape[0] != B or target.shape[1] != split + N_BOXES * 4:
         raise ValueError("target: expected [B, %d], got %s" % (split + N_BOXES * 4, tuple(target.shape)))
-    out5 = output.float().contiguous().view(B, S, S, 3, D)
-    tgt = target.float().contiguous()
+    tgt = target.detach().float().contiguous()
     # labels and boxes are read in place from the packed target rows (image stride = row length)
-    labels = tgt[:, :split]
-    bboxes = tgt[:, split:].unflatten(1, (N_BOXES, 4))
-    anc = _anchors_array(anchors)[scale]
-    out, _ = _launch(out5, 0, None, labels, tgt.shape[1], bboxes, tgt.shape[1], strides[scale], xyscale[scale], anc, iou_loss_threshold)
+    return tgt, tgt[:, :split], tgt[:, split:].unflatten(1, (N_BOXES, 4))
+
+
+class _LossAtScale(torch.autograd.Function):
+    """terms [3] = (giou, conf, prob) of one scale as a function of the head output."""
+
+    @staticmethod
+    def forward(ctx, output, target, scale, num_classes, strides, iou_loss_threshold, xyscale, anchors):
+        tgt, labels, bboxes = _split_target(target, output, num_classes)
+        B, S = output.shape[0], output.shape[1]
+        out5 = output.detach().float().contiguous().view(B, S, S, 3, 5 + num_classes)
+        anc = _anchors_array(anchors)[scale]
+        terms, _ = _launch(out5, 0, None, labels, tgt.shape[1], bboxes, tgt.shape[1], strides[scale], xyscale[scale], anc,
+                           iou_loss_threshold)
+        ctx.save_for_backward(out5, tgt)
+        ctx.cfg = (num_classes, float(strides[scale]), float(xyscale[scale]), anc, float(iou_loss_threshold), output.dtype)
+        return terms
+
+    @staticmethod
+    def backward(ctx, grad_terms):
+        out5, tgt = ctx.saved_tensors
+        C, stride, xys, anc, thr, dtype = ctx.cfg
+        B, S = out5.shape[0], out5.shape[1]
+        split = S * S * 3 * (5 + C)
+        wts = grad_terms.detach().float().contiguous()                  # upstream gradient of the three terms, stays on the GPU
+        ancf = (ctypes.c_float * 6)(*[float(v) for v in np.asarray(anc, np.float32).reshape(-1)[:6]])
+        dconv = torch.empty_like(out5)
+        labels, bboxes = tgt[:, :split], tgt[:, split:]
+        _lib.launch("ymx_yolo_loss_grad", dconv, _lib.ptr(out5), 0, _lib.ptr(labels), int(tgt.shape[1]), _lib.ptr(bboxes),
+                    int(tgt.shape[1]), B, S, C, N_BOXES, stride, xys, ancf, thr, _lib.ptr(wts), _lib.ptr(dconv))
+        return dconv.view(B, S, S, 3 * (5 + C)).to(dtype), None, None, None, None, None, None, None
+
+
+def loss_at_scale(target, output, scale, num_classes, strides, iou_loss_threshold, xyscale, anchors, terms=False):
+    """Body of one closure of get_yolo_loss_at_scales (losses.py:52-66) for ``scale``:
+    target [B, S*S*3*(5+C) + 128*4], output [B,S,S,3*(5+C)] -> giou + conf + prob (0-dim
+    tensor); with terms=True the three terms as a [3] tensor.  The decode of ``output``
+    (decode_train) happens inside the kernel.  Differentiable with respect to ``output``."""
+    _lib.require_gpu(target, output)
+    out = _LossAtScale.apply(output, target, scale, num_classes, strides, iou_loss_threshold, xyscale, anchors)
     return out if terms else out.sum()
 
 
