@@ -202,6 +202,11 @@ DMA_SHAPES = [
     (1, 2, 400, 32, 64, 3, False, "leaky", False),
     (1, 3, 123, 64, 128, 3, False, "mish", True),        # longest 64-channel row of the slab kernel
     (1, 3, 124, 64, 128, 3, False, "mish", False),
+    # rows beyond the 256-pixel form of the resident-slab kernel (W > 59): its 192-pixel form up to W = 91
+    (1, 5, 60, 64, 256, 3, False, "mish", True),
+    (1, 4, 76, 128, 256, 3, False, "mish", True),        # the 76-wide maps of a 608 x 608 input
+    (1, 3, 91, 64, 160, 3, False, "leaky", False),       # the widest row it takes
+    (1, 3, 92, 64, 256, 3, False, "mish", True),         # one past it: the streaming kernels
 ]
 
 

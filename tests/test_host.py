@@ -220,7 +220,9 @@ def _label(op):
 def test_kernel_selection_labels():
     """Which kernel family a layer is routed to, asked of the library (no GPU needed)."""
     assert _label(_conv_op(64, 52, 52, 512, 1024, 3)) == "halo"
-    assert _label(_conv_op(64, 76, 76, 512, 1024, 3)) == "dma"        # rows too long for two resident slabs
+    assert _label(_conv_op(64, 76, 76, 512, 1024, 3)) == "halo192"    # rows too long for two slabs of 256-pixel tiles
+    assert _label(_conv_op(32, 91, 91, 512, 1024, 3)) == "halo192"
+    assert _label(_conv_op(32, 92, 92, 512, 1024, 3)) == "dma"        # rows too long for two resident slabs of any tile
     assert _label(_conv_op(64, 13, 13, 512, 1024, 3)) == "halo192"    # 172 tiles of 256 pixels would idle a third of the CUs
     assert _label(_conv_op(64, 26, 26, 256, 512, 3)) == "halo192"     # 338 tiles: two rounds either way, shorter ones
     assert _label(_conv_op(64, 26, 26, 512, 1024, 3)) == "halo"

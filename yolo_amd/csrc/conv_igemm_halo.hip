@@ -32,7 +32,8 @@
 //
 // LDS: 2 slabs x ceil((258 + 2W) / 8) KB + 64 KB weight ring + 1 KB that absorbs the
 // no-op DMA instructions which keep the per-tile instruction count constant (the counted
-// vmcnt waits rely on it): W <= 59.
+// vmcnt waits rely on it): W <= 59 with 256-pixel tiles; 192-pixel tiles (slabs of
+// 194 + 2W rows, at most 47 KB each) reach W <= 91, e.g. the 76-wide maps of a 608 x 608 input.
 #include "conv_epilogue.h"
 
 namespace ymx {
@@ -263,7 +264,7 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
 // The shapes this kernel takes: 3x3, stride 1, whole 64-channel blocks, rows short enough
 // for two slabs to fit in LDS.
 bool conv_halo_eligible(const ConvArgs &a) {
-    return a.dtype == YMX_BF16 && a.k == 3 && a.stride == 1 && a.Cin % 64 == 0 && a.W <= 59;
+    return a.dtype == YMX_BF16 && a.k == 3 && a.stride == 1 && a.Cin % 64 == 0 && a.W <= 91;
 }
 
 thread_local int g_halo_pixels = 0;      // 0: pick the tile per layer; 256 / 192: force it (tuning option "halo_pixels")
@@ -274,6 +275,7 @@ thread_local int g_halo_pixels = 0;      // 0: pick the tile per layer; 256 / 19
 // behind the same barriers).  Layers with few tiles gain: 172 tiles of 256 pixels leave a
 // third of the CUs idle for a whole round where 228 tiles of 192 fill the chip for a shorter one.
 int conv_halo_tile_pixels(const ConvArgs &a) {
+    if (a.W > 59) return 192;                  // two slabs of a 256-pixel tile would not fit in LDS
     if (g_halo_pixels == 256 || g_halo_pixels == 192) return g_halo_pixels;
     const long long ntq = (a.Cout + 255) / 256;
     const long long r256 = (((long long)a.P + 255) / 256 * ntq + 255) / 256;
@@ -285,6 +287,7 @@ template <typename OT, int NJ>
 static int launch_halo_cfg(const ConvArgs &a, hipStream_t s) {
     constexpr int TP = 64 * NJ;
     const int npieces = (TP + 2 * a.W + 2 + 7) / 8;
+    if (npieces > 47) return fail(YMX_EUNSUPPORTED, "conv_igemm_halo: rows of %d pixels do not fit", a.W);
     int lds = 2 * npieces * 1024 + 4 * 128 * 128 + 1024;
     if (lds < 8 * EpiGeom<8, 64, 16 * NJ>::LDS_BYTES) lds = 8 * EpiGeom<8, 64, 16 * NJ>::LDS_BYTES;      // the epilogue's transpose images
     auto kern = conv_igemm_halo_kernel<OT, NJ>;
