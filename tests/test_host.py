@@ -180,6 +180,18 @@ for GB in (2 * WORLD + 3, 4 * WORLD, 1):  # uneven shards, even shards, ranks wi
     mine = Detections(*[t[s:s + c].clone() for t in full], full.keep_idx[s:s + c].clone())
     got = D.all_gather_detections(mine, GB)
     ok = ok and all(torch.equal(a, b) for a, b in zip(tuple(full) + (full.keep_idx,), tuple(got) + (got.keep_idx,)))
+# data-parallel gradient averaging: several buckets, two dtypes, gradients stay views of the buckets
+ps = [torch.nn.Parameter(torch.zeros(n)) for n in (5, 300, 7, 64)] + [torch.nn.Parameter(torch.zeros(3, 3, dtype=torch.float64))]
+gb = D.GradientBuckets(ps, bucket_bytes=1024)
+ok = ok and len(gb.buckets) >= 3
+for step in range(2):
+    gb.zero_()
+    for i, p in enumerate(ps):
+        p.grad.add_(torch.full_like(p, float((rank + 1) * (i + 1) + step)))      # what a backward pass would accumulate
+    gb.reduce().wait()
+    for i, p in enumerate(ps):
+        want = sum((r + 1) * (i + 1) + step for r in range(WORLD)) / WORLD
+        ok = ok and torch.allclose(p.grad, torch.full_like(p, want)) and p.grad.data_ptr() >= min(b.data_ptr() for b in gb.buckets)
 dist.barrier(); dist.destroy_process_group()
 sys.exit(0 if ok else 3)
 """
@@ -188,7 +200,8 @@ sys.exit(0 if ok else 3)
 @pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_all_gather_gloo(tmp_path, world):
     """Shard -> pack -> all-gather -> unpack over gloo at every world size the benchmark is
-    launched with: the gathered detections equal the unsharded ones bit for bit."""
+    launched with: the gathered detections equal the unsharded ones bit for bit.  Then the
+    bucketed gradient all-reduce of a training step: averages over the ranks, in place."""
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

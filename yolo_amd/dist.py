@@ -1,4 +1,5 @@
-"""Batch-sharded multi-GPU inference: one process per GPU, one all-gather at the end.
+"""Batch-sharded multi-GPU execution: one process per GPU; inference needs one all-gather
+at the end, a training step one bucketed all-reduce of the gradients (GradientBuckets).
 
 The reference has no multi-device code.  Images are independent through conv, decode,
 filter and NMS, so the global batch is split contiguously by rank, every rank runs the
@@ -79,3 +80,66 @@ def all_gather_detections(det, global_batch, group=None):
         _, cnt = shard_range(global_batch, r, world)
         parts.append(out[r, :cnt])
     return unpack_detections(torch.cat(parts, dim=0), t)
+
+
+class GradientBuckets(object):
+    """Data-parallel gradient averaging for a training step (the exchange a batch-sharded
+    training run needs; the reference has no multi-device code).
+
+    The gradients of ``params`` live in a few large flat buffers (``bucket_bytes`` each,
+    filled in reverse parameter order, the order back-propagation produces them);
+    ``p.grad`` of every parameter is a view into its bucket, so nothing is copied before or
+    after the collective.  ``reduce()`` starts one asynchronous all-reduce per bucket and
+    ``wait()`` finishes them and divides by the world size.  On RCCL a ring all-reduce moves
+    2 (n-1)/n of a bucket over each GPU's xGMI links; 64 MiB buckets keep the six collectives
+    of an 88 M-parameter fp32 model bandwidth-bound (about 0.5 ms each at 150 GB/s per link)
+    while leaving the first ones free to overlap with the rest of the backward pass."""
+
+    def __init__(self, params, bucket_bytes=64 << 20, group=None):
+        self.group = group
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []                       # flat tensors
+        self._handles = []
+        order = list(reversed(self.params))
+        i = 0
+        while i < len(order):
+            dtype, device = order[i].dtype, order[i].device
+            chunk, size = [], 0
+            while i < len(order) and order[i].dtype == dtype and order[i].device == device and \
+                    (not chunk or (size + order[i].numel()) * order[i].element_size() <= bucket_bytes):
+                chunk.append(order[i])
+                size += order[i].numel()
+                i += 1
+            flat = torch.zeros((size,), dtype=dtype, device=device)
+            off = 0
+            for p in chunk:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            self.buckets.append(flat)
+
+    def zero_(self):
+        for b in self.buckets:
+            b.zero_()
+
+    def reduce(self):
+        """Start the all-reduce of every bucket (in the order the backward pass fills them)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return self
+        for b in self.buckets:
+            t = b
+            if b.is_cuda and dist.get_backend(self.group) != "nccl":
+                t = b.cpu()                     # rehearsal backends reduce host tensors
+            self._handles.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), t, b))
+        return self
+
+    def wait(self):
+        """Finish the collectives; gradients become the average over the ranks."""
+        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        for h, t, b in self._handles:
+            h.wait()
+            if t is not b:
+                b.copy_(t)
+            if world > 1:
+                b.div_(world)
+        self._handles = []
+        return self
