@@ -291,6 +291,35 @@ int ymx_yolo_loss_grad(const float *conv, int conv_ld, const float *label, long 
                        float iou_loss_threshold, const float *term_weights /* device */,
                        float *dconv, void *stream);
 
+/* ---- backward pass of the convolution block ------------------------------------
+ * The reference trains through TensorFlow's automatic differentiation of YOLOConv /
+ * ResidialBlock / Upsample (layers.py:33-106); these are the pieces of that derivative.
+ * A training forward keeps the pre-activation z = conv(x) + bias (ymx_conv2d_fused with
+ * act = 0) and forms y = act(z) + residual with ymx_act_apply.  Given dy:
+ *   dz = dy * act'(z)                      ymx_act_backward   (act 0: dz = dy, no call needed)
+ *   dbias[c] = sum_p dz[p][c]              ymx_bias_grad      (two ordered stages, deterministic)
+ *   dkernel[r][s][ci][co] = sum_p x[p+(r,s)][ci] * dz[p][co]
+ *                                          ymx_conv_wgrad     (HWIO fp32, the layout of the kernel;
+ *                                          bf16 x and dz, channel counts multiples of 8; MFMA
+ *                                          with transposing LDS reads; pixel slices summed in order)
+ *   dx = conv(dz, kernel flipped in r,s and transposed in ci,co), for stride 2 on dz spread
+ *        over a zero map of the input's size (even rows / columns): the forward entry points
+ *   d residual = dy
+ * ymx_upsample2x_backward is the adjoint of ymx_upsample2x_concat's resize half: dx [B,H,W,C]
+ * from channels [c_off, c_off + C) of dy [B,2H,2W,dy_ld] (the skip half's gradient is the
+ * other channel slice of dy as it is).  n / n_pix count elements / pixels; ld strides are in
+ * elements, 0 = dense. */
+int ymx_act_apply(const void *z, const void *residual, void *y, long long n, int act, int dtype, void *stream);
+int ymx_act_backward(const void *z, const void *dy, void *dz, long long n, int act, int dtype, void *stream);
+size_t ymx_bias_grad_workspace_bytes(long long n_pix, int C);
+int ymx_bias_grad(const void *dz, long long n_pix, int C, int ld, int dtype, float *db,
+                  void *workspace, size_t ws_bytes, void *stream);
+size_t ymx_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride);
+int ymx_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw, int B, int H, int W,
+                   int Cin, int Cout, int k, int stride, void *workspace, size_t ws_bytes, void *stream);
+int ymx_upsample2x_backward(const void *dy, void *dx, int B, int H, int W, int C, int dy_ld, int c_off,
+                            int dtype, void *stream);
+
 /* ---- letterbox resize ---------------------------------------------------------
  * Replaces the image half of image_preprocess (utils.py:16-26): the image is resized by
  * scale = min(target/W, target/H) (bilinear, half-pixel centres, edges replicated: the

@@ -1,0 +1,161 @@
+"""GPU parity of the backward pass of the convolution blocks (yolo_amd.training) against
+torch's automatic differentiation of the CPU oracle (fp32 arithmetic on the same
+bf16-rounded inputs and weights).  bf16 tolerance: 1e-2 of each gradient tensor's scale for
+one block, looser bounds (stated per test) where several bf16 blocks are chained."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import net_torch as N
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _scaled_err(got, want):
+    return float((got.double() - want.double()).abs().max() / want.double().abs().max().clamp_min(1e-30))
+
+
+CASES = [   # B, H, W, Cin, Cout, k, downsample, act, shortcut
+    (2, 13, 11, 64, 128, 3, False, "mish", True),
+    (3, 16, 16, 32, 64, 3, True, "mish", False),          # stride 2: 16 -> 8
+    (2, 10, 12, 128, 64, 1, False, "leaky", False),
+    (1, 26, 26, 256, 255, 1, False, None, False),         # a head's output convolution: 255 channels, linear
+    (2, 9, 7, 16, 24, 3, False, "mish", True),            # partial tiles everywhere
+    (1, 40, 40, 64, 192, 3, False, "leaky", True),        # several pixel slices
+    (2, 15, 15, 64, 32, 3, True, "mish", False),          # stride 2 on an odd size: 15 -> 7
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_conv_block_gradients(case):
+    from yolo_amd import training as T
+    from yolo_amd.layers import YOLOConv
+    B, H, W, cin, cout, k, down, act, use_sc = CASES[case]
+    g = torch.Generator().manual_seed(500 + case)
+    x = N.bf16_round(torch.randn(B, H, W, cin, generator=g))
+    p = {"kernel": N.bf16_round(torch.randn(k, k, cin, cout, generator=g) * (2.0 / (k * k * cin)) ** 0.5),
+         "bias": N.bf16_round(0.1 * torch.randn(cout, generator=g))}
+    # oracle: fp32 autograd
+    xo = x.clone().requires_grad_(True)
+    po = {n: v.clone().requires_grad_(True) for n, v in p.items()}
+    yo = N.yolo_conv(xo, po, down, act)
+    sc = N.bf16_round(torch.randn(*yo.shape, generator=g)) if use_sc else None
+    sco = None
+    if use_sc:
+        sco = sc.clone().requires_grad_(True)
+        yo = yo + sco
+    G = N.bf16_round(torch.randn(*yo.shape, generator=g))
+    (yo * G).sum().backward()
+    # GPU
+    layer = YOLOConv((k, k, cout), downsample=down, activation=act, dtype=torch.bfloat16)
+    layer.load_reference_params(p)
+    layer.to(DEV)
+    xg = x.to(DEV).bfloat16().requires_grad_(True)
+    scg = sc.to(DEV).bfloat16().requires_grad_(True) if use_sc else None
+    with T.backprop():
+        yg = layer(xg, residual=scg)
+    assert yg.requires_grad and yg.dtype == torch.bfloat16
+    assert _scaled_err(yg.detach().float().cpu(), yo.detach()) < 1e-2
+    (yg.float() * G.to(DEV)).sum().backward()
+    assert layer.kernel.grad.shape == p["kernel"].shape and layer.kernel.grad.dtype == torch.float32
+    errs = {"kernel": _scaled_err(layer.kernel.grad.cpu(), po["kernel"].grad), "bias": _scaled_err(layer.bias.grad.cpu(), po["bias"].grad),
+            "x": _scaled_err(xg.grad.float().cpu(), xo.grad)}
+    if use_sc:
+        errs["shortcut"] = _scaled_err(scg.grad.float().cpu(), sco.grad)
+    print("conv block gradient errors (of each tensor's scale):", errs)
+    for name, e in errs.items():
+        assert e < 1e-2, (name, e)
+    # outside the context nothing is recorded and the fused inference kernels run
+    y_inf = layer(xg.detach(), residual=None if scg is None else scg.detach())
+    assert not y_inf.requires_grad
+
+
+def test_upsample_concat_gradient():
+    from yolo_amd import training as T
+    from yolo_amd.layers import upsample2x_concat
+    g = torch.Generator().manual_seed(9)
+    for (B, H, W, c1, c2) in ((2, 5, 7, 16, 24), (1, 13, 13, 0, 8), (1, 1, 1, 8, 8)):
+        x = N.bf16_round(torch.randn(B, H, W, c2, generator=g))
+        skip = N.bf16_round(torch.randn(B, 2 * H, 2 * W, c1, generator=g)) if c1 else None
+        G = N.bf16_round(torch.randn(B, 2 * H, 2 * W, c1 + c2, generator=g))
+        xo = x.clone().requires_grad_(True)
+        up = N.upsample2x(xo)
+        so = None
+        if c1:
+            so = skip.clone().requires_grad_(True)
+            up = torch.cat([so, up], dim=-1)
+        (up * G).sum().backward()
+        for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+            xg = x.to(DEV).to(dt).requires_grad_(True)
+            sg = skip.to(DEV).to(dt).requires_grad_(True) if c1 else None
+            with T.backprop():
+                y = upsample2x_concat(sg, xg)
+            (y.float() * G.to(DEV)).sum().backward()
+            assert _scaled_err(xg.grad.float().cpu(), xo.grad) < tol
+            if c1:
+                assert _scaled_err(sg.grad.float().cpu(), so.grad) < tol
+
+
+def test_small_network_gradients_and_descent():
+    """A stride-2 conv, a ResidialBlock, an upsample + concat and a linear output conv chained:
+    every parameter gradient against the oracle's autograd (3e-2 of its scale: three to four
+    bf16 blocks deep), and a few steps of gradient descent on the GPU lower the loss."""
+    from yolo_amd import training as T
+    from yolo_amd.layers import YOLOConv, ResidialBlock, upsample2x_concat
+    g = torch.Generator().manual_seed(77)
+    specs = [(3, 16, 32, True, "mish"), (1, 32, 16, False, "mish"), (3, 16, 32, False, "mish"), (1, 48, 24, False, None)]
+    params = []
+    for k, cin, cout, down, act in specs:
+        params.append({"kernel": N.bf16_round(torch.randn(k, k, cin, cout, generator=g) * (2.0 / (k * k * cin)) ** 0.5),
+                       "bias": N.bf16_round(0.05 * torch.randn(cout, generator=g))})
+    x = N.bf16_round(torch.randn(2, 12, 12, 16, generator=g))
+    target = torch.randn(2, 12, 12, 24, generator=g)
+
+    def oracle():
+        ps = [{n: v.clone().requires_grad_(True) for n, v in p.items()} for p in params]
+        a = N.yolo_conv(x, ps[0], True, "mish")                                  # 12 -> 6
+        b = a + N.yolo_conv(N.yolo_conv(a, ps[1], False, "mish"), ps[2], False, "mish")
+        c = torch.cat([x, N.upsample2x(b)], dim=-1)                             # 16 + 32 channels at 12 x 12
+        out = N.yolo_conv(c, ps[3], False, None)
+        loss = ((out - target) ** 2).mean()
+        loss.backward()
+        return float(loss.detach()), ps
+
+    want_loss, ps = oracle()
+    first = YOLOConv((3, 3, 32), downsample=True, dtype=torch.bfloat16)
+    block = ResidialBlock(16, 32, dtype=torch.bfloat16)
+    last = YOLOConv((1, 1, 24), activation=None, dtype=torch.bfloat16)
+    layers = [first, block.layer_stack[0], block.layer_stack[1], last]
+    for layer, p in zip(layers, params):
+        layer.load_reference_params(p)
+        layer.to(DEV)
+    xg = x.to(DEV).bfloat16()
+    tg = target.to(DEV)
+
+    def step():
+        with T.backprop():
+            a = first(xg)
+            b = block(a)
+            out = last(upsample2x_concat(xg, b))
+        loss = ((out.float() - tg) ** 2).mean()
+        for layer in layers:
+            layer.kernel.grad = None
+            layer.bias.grad = None
+        loss.backward()
+        return float(loss)
+
+    got_loss = step()
+    assert abs(got_loss - want_loss) < 2e-2 * abs(want_loss)
+    for layer, p in zip(layers, ps):
+        for name in ("kernel", "bias"):
+            e = _scaled_err(getattr(layer, name).grad.cpu(), p[name].grad)
+            assert e < 3e-2, (name, tuple(p[name].shape), e)
+    losses = [got_loss]
+    for _ in range(5):
+        with torch.no_grad():
+            for layer in layers:
+                layer.kernel -= 0.05 * layer.kernel.grad
+                layer.bias -= 0.05 * layer.bias.grad
+        losses.append(step())
+    assert losses[-1] < 0.9 * losses[0], losses

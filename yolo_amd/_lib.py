@@ -59,6 +59,13 @@ SIGNATURES = {
     "ymx_spp_concat": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ymx_yolo_loss_grad": (_i, [_vp, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _i, _i, _i, _i, _f, _f, ctypes.POINTER(_f), _f,
                                 _vp, _vp, _vp]),
+    "ymx_act_apply": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp]),
+    "ymx_act_backward": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp]),
+    "ymx_bias_grad_workspace_bytes": (_sz, [ctypes.c_longlong, _i]),
+    "ymx_bias_grad": (_i, [_vp, ctypes.c_longlong, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "ymx_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "ymx_conv_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "ymx_upsample2x_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ymx_letterbox": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "ymx_draw_boxes": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "ymx_yolo_loss_workspace_bytes": (_sz, [_i, _i]),

@@ -434,6 +434,67 @@ int ymx_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dtype
     return launch_spp_concat(x, y, B, H, W, C, dtype, (hipStream_t)stream);
 }
 
+int ymx_act_apply(const void *z, const void *residual, void *y, long long n, int act, int dtype, void *stream) {
+    if (!z || !y) return fail(YMX_EARG, "act_apply: null pointer");
+    if (n <= 0) return fail(YMX_EARG, "act_apply: non-positive size");
+    if (act < 0 || act > 2) return fail(YMX_EARG, "act_apply: activation %d", act);
+    if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "act_apply: dtype %d", dtype);
+    return launch_act(z, residual, y, (size_t)n, act, dtype, 0, (hipStream_t)stream);
+}
+
+int ymx_act_backward(const void *z, const void *dy, void *dz, long long n, int act, int dtype, void *stream) {
+    if (!z || !dy || !dz) return fail(YMX_EARG, "act_backward: null pointer");
+    if (n <= 0) return fail(YMX_EARG, "act_backward: non-positive size");
+    if (act < 0 || act > 2) return fail(YMX_EARG, "act_backward: activation %d", act);
+    if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "act_backward: dtype %d", dtype);
+    return launch_act(z, dy, dz, (size_t)n, act, dtype, 1, (hipStream_t)stream);
+}
+
+size_t ymx_bias_grad_workspace_bytes(long long n_pix, int C) { return (n_pix > 0 && C > 0) ? bias_grad_workspace_bytes(n_pix, C) : 0; }
+
+int ymx_bias_grad(const void *dz, long long n_pix, int C, int ld, int dtype, float *db, void *workspace, size_t ws_bytes, void *stream) {
+    if (!dz || !db) return fail(YMX_EARG, "bias_grad: null pointer");
+    if (n_pix <= 0 || C <= 0) return fail(YMX_EARG, "bias_grad: non-positive size");
+    if (ld != 0 && ld < C) return fail(YMX_EARG, "bias_grad: row stride below the channel count");
+    if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "bias_grad: dtype %d", dtype);
+    const size_t need = bias_grad_workspace_bytes(n_pix, C);
+    if (!workspace || ws_bytes < need) return fail(YMX_EWORKSPACE, "bias_grad: workspace %zu < %zu bytes", ws_bytes, need);
+    return launch_bias_grad(dz, n_pix, C, ld ? ld : C, dtype, db, workspace, (hipStream_t)stream);
+}
+
+static long long wgrad_pixels(int B, int H, int W, int k, int stride) {
+    const int oh = stride == 1 ? H : (H + 1 - k) / 2 + 1, ow = stride == 1 ? W : (W + 1 - k) / 2 + 1;
+    return (long long)B * oh * ow;
+}
+
+size_t ymx_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2)) return 0;
+    return conv_wgrad_workspace_bytes(k, Cin, Cout, wgrad_pixels(B, H, W, k, stride));
+}
+
+int ymx_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw, int B, int H, int W, int Cin, int Cout, int k,
+                   int stride, void *workspace, size_t ws_bytes, void *stream) {
+    if (!x || !dz || !dw) return fail(YMX_EARG, "conv_wgrad: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(YMX_EARG, "conv_wgrad: non-positive size");
+    if ((k != 1 && k != 3) || (stride != 1 && stride != 2)) return fail(YMX_EUNSUPPORTED, "conv_wgrad: k=%d stride=%d", k, stride);
+    if (stride == 2 && ((H + 1 - k) < 0 || (W + 1 - k) < 0)) return fail(YMX_EARG, "conv_wgrad: input smaller than the kernel");
+    if (Cin % 8 || Cout % 8) return fail(YMX_EUNSUPPORTED, "conv_wgrad: channel counts must be multiples of 8 (pad them), got %d -> %d", Cin, Cout);
+    if ((x_ld != 0 && (x_ld < Cin || x_ld % 8)) || (dz_ld != 0 && (dz_ld < Cout || dz_ld % 8))) return fail(YMX_EARG, "conv_wgrad: pixel strides must be multiples of 8 elements");
+    if (!aligned16(x) || !aligned16(dz) || (((uintptr_t)dw) & 3)) return fail(YMX_EARG, "conv_wgrad: alignment");
+    if ((long long)B * H * W * (x_ld ? x_ld : Cin) >= (1LL << 40)) return fail(YMX_EUNSUPPORTED, "conv_wgrad: input too large");
+    const size_t need = conv_wgrad_workspace_bytes(k, Cin, Cout, wgrad_pixels(B, H, W, k, stride));
+    if (need && (!workspace || ws_bytes < need)) return fail(YMX_EWORKSPACE, "conv_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+    return launch_conv_wgrad(x, x_ld, dz, dz_ld, dw, B, H, W, Cin, Cout, k, stride, workspace, (hipStream_t)stream);
+}
+
+int ymx_upsample2x_backward(const void *dy, void *dx, int B, int H, int W, int C, int dy_ld, int c_off, int dtype, void *stream) {
+    if (!dy || !dx) return fail(YMX_EARG, "upsample2x_backward: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || c_off < 0) return fail(YMX_EARG, "upsample2x_backward: bad size");
+    if (dy_ld != 0 && dy_ld < c_off + C) return fail(YMX_EARG, "upsample2x_backward: row stride below the channels read");
+    if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "upsample2x_backward: dtype %d", dtype);
+    return launch_upsample2x_bwd(dy, dx, B, H, W, C, dy_ld ? dy_ld : c_off + C, c_off, dtype, (hipStream_t)stream);
+}
+
 int ymx_yolo_loss_grad(const float *conv, int conv_ld, const float *label, long long label_stride, const float *bboxes,
                        long long bbox_stride, int B, int S, int C, int n_boxes, float stride, float xyscale, const float *anchors,
                        float iou_loss_threshold, const float *term_weights, float *dconv, void *stream) {

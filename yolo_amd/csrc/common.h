@@ -226,6 +226,13 @@ int launch_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dt
 int launch_letterbox(const void *src, int in_u8, int B, int H, int W, void *dst, int out_bf16, int T, int literal, hipStream_t s);
 int launch_draw_boxes(unsigned char *img, int B, int H, int W, const float *boxes, const float *classes, const int *valid, int M,
                       const unsigned char *colors, int C, int thick, hipStream_t s);
+int launch_act(const void *z, const void *other, void *y, size_t n, int act, int dtype, int mode, hipStream_t s);
+size_t bias_grad_workspace_bytes(long long P, int C);
+int launch_bias_grad(const void *dz, long long P, int C, int ld, int dtype, float *db, void *ws, hipStream_t s);
+size_t conv_wgrad_workspace_bytes(int k, int Cin, int Cout, long long P);
+int launch_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw, int B, int H, int W, int Cin, int Cout, int k,
+                      int stride, void *ws, hipStream_t s);
+int launch_upsample2x_bwd(const void *dy, void *dx, int B, int H, int W, int C, int dy_ld, int c_off, int dtype, hipStream_t s);
 size_t yolo_loss_workspace_bytes(int B, int S);
 int launch_yolo_loss_grad(const float *conv, int conv_ld, const float *label, long long label_stride, const float *bboxes,
                           long long bbox_stride, int B, int S, int C, int NB, float stride, float xyscale, const float *anchors,

@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from . import training as _training
 
 BN_EPSILON = 1e-3      # Keras BatchNormalization default, used unchanged at layers.py:4
 
@@ -101,8 +102,10 @@ class RouteGroup(nn.Module):
         return torch.split(x, c // self.groups, dim=-1)[self.group_id]
 
 
-def upsample2x_concat(skip, x):
+def upsample2x_concat(skip, x, _differentiable=True):
     """[skip, bilinear_x2(x)] along channels in one kernel (ymx_upsample2x_concat)."""
+    if _differentiable and _training.enabled():
+        return _training.upsample_concat(skip, x)
     x = _as_nhwc(x)
     b, h, w, c2 = x.shape
     c1 = 0
@@ -249,6 +252,12 @@ class YOLOConv(nn.Module):
             self.to(x.device)
         if x.shape[-1] != self.in_channels:
             raise ValueError("YOLOConv %s: expected %d input channels, got %d" % (self.name or "", self.in_channels, x.shape[-1]))
+        if _training.enabled():
+            # differentiable path (yolo_amd.training): z = conv(x) kept, y = act(z) + shortcut
+            if out is not None:
+                raise ValueError("YOLOConv: out= is not supported while back-propagation is recorded")
+            y = _training.conv_block(self, x, residual)
+            return y if out_dtype in (None, y.dtype) else y.to(out_dtype)
         cdt = self.compute_dtype or x.dtype
         code = _lib.dtype_code(cdt)
         k, cin, cout = self.kernel_size, self.in_channels, self.filters

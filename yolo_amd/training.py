@@ -1,0 +1,206 @@
+"""Back-propagation through the convolution blocks (bf16 networks).
+
+The reference trains by letting TensorFlow differentiate YOLOConv / ResidialBlock / Upsample
+(/root/reference/layers.py:33-106) under ``model.fit``.  Here ``torch.autograd`` only keeps the
+graph (which tensor feeds which, summing gradients where a tensor is used twice, e.g. the
+shortcut of a ResidialBlock); every forward and backward step of a block is a launch of
+libymx:
+
+  forward   z = conv(x) + bias            ymx_conv2d_fused_ex, no activation (z is kept)
+            y = act(z) + shortcut         ymx_act_apply
+  backward  dz = dy * act'(z)             ymx_act_backward
+            dbias = sum_p dz              ymx_bias_grad
+            dkernel = x (*) dz            ymx_conv_wgrad (HWIO fp32, the kernel's own layout)
+            dx = conv(dz, kernel flipped and transposed)      the forward kernels again
+            dshortcut = dy
+
+Use::
+
+    with yolo_amd.training.backprop():
+        heads = head(*backbone(images))
+        loss = sum(f(t, o) for f, t, o in zip(loss_fns, targets, heads[::-1]))
+    loss.backward()              # .grad of every kernel and bias, fp32
+
+Outside the context (the default) the layers run the fused inference kernels and build no
+graph.  Batch normalisation in training mode is not provided (the networks of the reference
+use bias, layers.py:61).
+"""
+import threading
+
+import torch
+
+from . import _lib
+
+_state = threading.local()
+
+
+def enabled():
+    return getattr(_state, "on", False) and torch.is_grad_enabled()
+
+
+class backprop(object):
+    """Context manager: YOLOConv and upsample2x_concat record a differentiable graph."""
+
+    def __enter__(self):
+        self._prev = getattr(_state, "on", False)
+        _state.on = True
+        return self
+
+    def __exit__(self, *exc):
+        _state.on = self._prev
+        return False
+
+
+def _empty(shape, like, dtype=None):
+    return torch.empty(shape, device=like.device, dtype=dtype or like.dtype)
+
+
+def _pad_channels(t, mult=8):
+    """[..., C] -> [..., C rounded up to a multiple of mult] (zeros), contiguous."""
+    c = t.shape[-1]
+    cp = -(-c // mult) * mult
+    if cp == c:
+        return t.contiguous()
+    out = torch.zeros(t.shape[:-1] + (cp,), device=t.device, dtype=t.dtype)
+    out[..., :c] = t
+    return out
+
+
+def _pack(kernel_hwio, dtype):
+    k, _, cin, cout = kernel_hwio.shape
+    code = _lib.dtype_code(dtype)
+    src = kernel_hwio.detach().float().contiguous()
+    wp = torch.empty(_lib.lib().ymx_packed_weight_bytes(k, cin, cout, code), dtype=torch.uint8, device=src.device)
+    _lib.launch("ymx_pack_weights", wp, _lib.ptr(src), _lib.ptr(wp), k, cin, cout, code)
+    return wp, src
+
+
+def _conv(x, wp, shift, cin, cout, k, stride, cdt, odt):
+    b, h, w, _ = x.shape
+    oh, ow = (h, w) if stride == 1 else ((h + 1 - k) // 2 + 1, (w + 1 - k) // 2 + 1)
+    y = _empty((b, oh, ow, cout), x, odt)
+    code = _lib.dtype_code(cdt)
+    _lib.launch("ymx_conv2d_fused_ex", x, _lib.ptr(x), _lib.ptr(wp), None, _lib.ptr(shift), None, _lib.ptr(y), b, h, w, cin, cout,
+                k, stride, _lib.ACT_NONE, code, _lib.dtype_code(x.dtype), _lib.dtype_code(odt), 0, 0, 0)
+    return y
+
+
+class _ConvBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, bias, shortcut, layer):
+        cdt = layer.compute_dtype or x.dtype
+        if cdt != torch.bfloat16:
+            raise ValueError("yolo_amd.training: back-propagation is provided for bfloat16 networks")
+        k, cin, cout = layer.kernel_size, layer.in_channels, layer.filters
+        stride = 2 if layer.downsample else 1
+        x = x.contiguous()
+        if cin % 8 == 0 and x.dtype != cdt:
+            x = x.to(cdt)
+        entry = layer.packed(cdt)
+        wp, shift = entry[0], entry[2]
+        z = _conv(x, wp, shift, cin, cout, k, stride, cdt, cdt)
+        if layer.act_code != _lib.ACT_NONE or shortcut is not None:
+            y = torch.empty_like(z)
+            sc = None if shortcut is None else shortcut.to(cdt).contiguous()
+            _lib.launch("ymx_act_apply", z, _lib.ptr(z), _lib.ptr(sc), _lib.ptr(y), z.numel(), layer.act_code, _lib.dtype_code(cdt))
+        else:
+            y = z
+        ctx.save_for_backward(x, z, kernel)
+        ctx.layer = layer
+        ctx.has_shortcut = shortcut is not None
+        ctx.shortcut_dtype = None if shortcut is None else shortcut.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, kernel = ctx.saved_tensors
+        layer = ctx.layer
+        cdt = torch.bfloat16
+        code = _lib.dtype_code(cdt)
+        k, cin, cout = layer.kernel_size, layer.in_channels, layer.filters
+        stride = 2 if layer.downsample else 1
+        b, h, w, _ = x.shape
+        oh, ow = z.shape[1], z.shape[2]
+        dy = dy.to(cdt).contiguous()
+        if layer.act_code != _lib.ACT_NONE:
+            dz = torch.empty_like(z)
+            _lib.launch("ymx_act_backward", z, _lib.ptr(z), _lib.ptr(dy), _lib.ptr(dz), z.numel(), layer.act_code, code)
+        else:
+            dz = dy
+        L = _lib.lib()
+        npix = b * oh * ow
+        # bias
+        dbias = None
+        if ctx.needs_input_grad[2]:
+            dbias = torch.empty((cout,), device=x.device, dtype=torch.float32)
+            nb = L.ymx_bias_grad_workspace_bytes(npix, cout)
+            ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)
+            _lib.launch("ymx_bias_grad", dz, _lib.ptr(dz), npix, cout, 0, code, _lib.ptr(dbias), _lib.ptr(ws), nb)
+        # channel counts the MFMA kernels take (multiples of 8): zero padding changes nothing
+        dzp = _pad_channels(dz)
+        coutp = dzp.shape[-1]
+        dkernel = None
+        if ctx.needs_input_grad[1]:
+            xp = _pad_channels(x.to(cdt))
+            cinp = xp.shape[-1]
+            dwp = torch.empty((k, k, cinp, coutp), device=x.device, dtype=torch.float32)
+            nb = L.ymx_conv_wgrad_workspace_bytes(b, h, w, cinp, coutp, k, stride)
+            ws = torch.empty((max(nb, 16),), device=x.device, dtype=torch.uint8)
+            _lib.launch("ymx_conv_wgrad", xp, _lib.ptr(xp), 0, _lib.ptr(dzp), 0, _lib.ptr(dwp), b, h, w, cinp, coutp, k, stride,
+                        _lib.ptr(ws), nb)
+            dkernel = dwp[:, :, :cin, :cout]
+            if dkernel.shape != dwp.shape:
+                dkernel = dkernel.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # d loss / d x = conv(dz, kernel flipped over the taps, input and output channels swapped)
+            wd = kernel.detach().flip(0, 1).permute(0, 1, 3, 2)
+            if coutp != cout:
+                wd = torch.cat([wd, torch.zeros((k, k, coutp - cout, cin), device=wd.device, dtype=wd.dtype)], dim=2)
+            wdp, _keep = _pack(wd, cdt)
+            src = dzp
+            if stride == 2:
+                if k != 3:
+                    raise ValueError("yolo_amd.training: stride-2 convolutions are 3x3")
+                src = torch.zeros((b, h, w, coutp), device=x.device, dtype=cdt)       # dz on the even rows / columns
+                src[:, 0:2 * oh:2, 0:2 * ow:2] = dzp
+            dx = _conv(src, wdp, None, coutp, cin, k, 1, cdt, cdt)
+        dshortcut = None
+        if ctx.has_shortcut and ctx.needs_input_grad[3]:
+            dshortcut = dy.to(ctx.shortcut_dtype)
+        return dx, dkernel, dbias, dshortcut, None
+
+
+def conv_block(layer, x, shortcut=None):
+    """YOLOConv forward that autograd can differentiate (called by YOLOConv.forward inside
+    ``backprop()``)."""
+    if layer.batch_normalization:
+        raise ValueError("yolo_amd.training: batch normalisation in training mode is not provided")
+    if layer.act_fn is not None:
+        raise ValueError("yolo_amd.training: callable activations are not differentiated")
+    return _ConvBlock.apply(x, layer.kernel, layer.bias, shortcut, layer)
+
+
+class _UpsampleConcat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, skip, x):
+        from .layers import upsample2x_concat
+        ctx.c1 = 0 if skip is None else skip.shape[-1]
+        ctx.xshape = tuple(x.shape)
+        return upsample2x_concat(skip, x, _differentiable=False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        b, h, w, c2 = ctx.xshape
+        c1 = ctx.c1
+        dskip = dy[..., :c1].contiguous() if (c1 and ctx.needs_input_grad[0]) else None
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = torch.empty(ctx.xshape, device=dy.device, dtype=dy.dtype)
+            _lib.launch("ymx_upsample2x_backward", dy, _lib.ptr(dy), _lib.ptr(dx), b, h, w, c2, c1 + c2, c1, _lib.dtype_code(dy.dtype))
+        return dskip, dx
+
+
+def upsample_concat(skip, x):
+    return _UpsampleConcat.apply(skip, x)
