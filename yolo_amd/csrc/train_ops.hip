@@ -50,7 +50,42 @@ act_kernel(const T *__restrict__ z, const T *__restrict__ other, T *__restrict__
     }
 }
 
+// bf16, eight values per thread (16-byte loads and stores); n is a multiple of 8 here
+template <int MODE>
+__global__ void __launch_bounds__(256)
+act_kernel_bf16x8(const uint4 *__restrict__ z, const uint4 *__restrict__ other, uint4 *__restrict__ y, size_t n8, int act) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const uint4 zv = z[i];
+        uint4 ov = make_uint4(0u, 0u, 0u, 0u);
+        if (MODE == 1 || other) ov = other[i];
+        const uint32_t zw[4] = {zv.x, zv.y, zv.z, zv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
+        uint32_t r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float z0 = __uint_as_float(zw[k] << 16), z1 = __uint_as_float(zw[k] & 0xffff0000u);
+            const float o0 = __uint_as_float(ow[k] << 16), o1 = __uint_as_float(ow[k] & 0xffff0000u);
+            float a0, a1;
+            if (MODE == 0) {
+                a0 = act_f(z0, act) + o0;
+                a1 = act_f(z1, act) + o1;
+            } else {
+                a0 = o0 * (act == 2 ? mish_grad_f(z0) : (act == 1 ? (z0 > 0.0f ? 1.0f : 0.1f) : 1.0f));
+                a1 = o1 * (act == 2 ? mish_grad_f(z1) : (act == 1 ? (z1 > 0.0f ? 1.0f : 0.1f) : 1.0f));
+            }
+            r[k] = pack2_bf16(a0, a1);
+        }
+        y[i] = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+}
+
 int launch_act(const void *z, const void *other, void *y, size_t n, int act, int dtype, int mode, hipStream_t s) {
+    if (dtype == YMX_BF16 && n % 8 == 0 && aligned16(z) && aligned16(y) && aligned16(other)) {
+        const size_t n8 = n / 8;
+        const int grid8 = (int)std::min<size_t>((n8 + 255) / 256, 1 << 16);
+        if (mode == 0) hipLaunchKernelGGL(act_kernel_bf16x8<0>, dim3(grid8), dim3(256), 0, s, (const uint4 *)z, (const uint4 *)other, (uint4 *)y, n8, act);
+        else hipLaunchKernelGGL(act_kernel_bf16x8<1>, dim3(grid8), dim3(256), 0, s, (const uint4 *)z, (const uint4 *)other, (uint4 *)y, n8, act);
+        return check_launch("act");
+    }
     const int grid = (int)std::min<size_t>((n + 255) / 256, 1 << 16);
     if (dtype == YMX_BF16) {
         if (mode == 0) hipLaunchKernelGGL((act_kernel<bf16_t, 0>), dim3(grid), dim3(256), 0, s, (const bf16_t *)z, (const bf16_t *)other, (bf16_t *)y, n, act);
@@ -79,16 +114,56 @@ colsum_kernel(const T *__restrict__ x, float *__restrict__ partial, long long P,
 
 __global__ void __launch_bounds__(256)
 sum_partials_kernel(const float *__restrict__ partial, float *__restrict__ out, size_t n, int parts) {
+    // four running sums over parts s = 0, 1, 2, 3 (mod 4), added at the end: a fixed order, and
+    // the loads of a thread do not wait for one another
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float acc = 0.0f;
-        for (int s = 0; s < parts; ++s) acc += partial[(size_t)s * n + i];
-        out[i] = acc;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        int s = 0;
+        for (; s + 4 <= parts; s += 4) {
+            const float v0 = partial[(size_t)s * n + i], v1 = partial[(size_t)(s + 1) * n + i];
+            const float v2 = partial[(size_t)(s + 2) * n + i], v3 = partial[(size_t)(s + 3) * n + i];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; s < parts; ++s) a0 += partial[(size_t)s * n + i];
+        out[i] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+// bf16 rows whose 16-byte chunks divide the workgroup (C / 8 a power of two up to 256, dense
+// or padded rows): thread = (row lane, chunk); every thread sums its chunk's eight channels
+// over the slab's rows in steps of 256 / chunks rows, the row lanes are then added in LDS in
+// a fixed order.
+__global__ void __launch_bounds__(256)
+colsum_bf16_kernel(const bf16_t *__restrict__ x, float *__restrict__ partial, long long P, int C, int ld, long long rows_per) {
+    __shared__ float red[256 * 8];
+    const int nch = C >> 3, t = threadIdx.x;
+    const int ch = t % nch, rl = t / nch, nrl = 256 / nch;
+    const long long r0 = (long long)blockIdx.x * rows_per;
+    const long long r1 = r0 + rows_per < P ? r0 + rows_per : P;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long long r = r0 + rl; r < r1; r += nrl) {
+        const uint4 v = *(const uint4 *)(x + (size_t)r * ld + ch * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[2 * k] += __uint_as_float(w[k] << 16);
+            acc[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[t * 8 + k] = acc[k];
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        const int cch = c >> 3, k = c & 7;
+        float sum = 0.0f;
+        for (int l = 0; l < nrl; ++l) sum += red[(l * nch + cch) * 8 + k];
+        partial[(size_t)blockIdx.x * C + c] = sum;
     }
 }
 
 static int colsum_parts(long long P) {
     long long parts = (P + 511) / 512;
-    return (int)(parts > 1024 ? 1024 : (parts < 1 ? 1 : parts));
+    return (int)(parts > 512 ? 512 : (parts < 1 ? 1 : parts));
 }
 size_t bias_grad_workspace_bytes(long long P, int C) { return (size_t)colsum_parts(P) * C * 4; }
 
@@ -96,7 +171,10 @@ int launch_bias_grad(const void *dz, long long P, int C, int ld, int dtype, floa
     const int parts = colsum_parts(P);
     const long long rows_per = (P + parts - 1) / parts;
     float *partial = (float *)ws;
-    if (dtype == YMX_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(parts), dim3(256), 0, s, (const bf16_t *)dz, partial, P, C, ld, rows_per);
+    const int nch = C / 8;
+    const bool fast = dtype == YMX_BF16 && C % 8 == 0 && nch <= 256 && (nch & (nch - 1)) == 0 && ld % 8 == 0 && aligned16(dz);
+    if (fast) hipLaunchKernelGGL(colsum_bf16_kernel, dim3(parts), dim3(256), 0, s, (const bf16_t *)dz, partial, P, C, ld, rows_per);
+    else if (dtype == YMX_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(parts), dim3(256), 0, s, (const bf16_t *)dz, partial, P, C, ld, rows_per);
     else hipLaunchKernelGGL(colsum_kernel<float>, dim3(parts), dim3(256), 0, s, (const float *)dz, partial, P, C, ld, rows_per);
     int rc = check_launch("bias_grad");
     if (rc) return rc;
@@ -111,73 +189,100 @@ int launch_bias_grad(const void *dz, long long P, int C, int ld, int dtype, floa
 // memory, [pixel][channel] rows, and read with the transposing LDS read of gfx950
 // (ds_read_b64_tr_b16: per 16-lane group a block of 4 rows x 16 columns arrives column-major),
 // two reads per operand fragment.
-// Workgroup = 4 waves = tile of 64 input channels x 128 output channels of one tap and one
-// slice of the pixels; wave w owns output channels [32 w, 32 w + 32).  Per step 64 pixels:
-// the next step's rows are loaded into registers while the MFMAs of the current one run.
-// Slices (grid.z) write separate partial results that a second kernel adds in order, so the
-// result is reproducible.
+// Workgroup = 4 waves = tile of TCI (64 or 128) input channels x 128 output channels of one
+// tap and one slice of the pixels; the waves split it 1 x 4 (64 x 32 each) or 2 x 2 (64 x 64
+// each).  Per step 64 pixels: the next step's rows are loaded into registers while the MFMAs
+// of the current one run.  Slices (grid.z) write separate partial results that a second
+// kernel adds in order, so the result is reproducible.
 struct WgradArgs {
     const bf16_t *x, *dz;
     float *out;                 // [splits][k*k][Cin][Cout]
     int B, H, W, Cin, OH, OW, Cout, k, stride, pad;
     int x_ld, dz_ld;
-    long long P;                // B * OH * OW
-    long long chunks_per_split; // 64-pixel chunks per slice
+    int P;                      // B * OH * OW
+    int chunks_per_split;       // 64-pixel chunks per slice
     int n_ci_tiles;
+    unsigned ow_m, ow_s, ohw_m, ohw_s;     // fastdiv constants of OW and OH * OW
 };
 
-constexpr int WG_PA = 64 * 2 + 16;       // LDS row pitch of the X tile: 64 channels + 16 bytes
-constexpr int WG_PB = 128 * 2 + 16;      // dZ tile: 128 channels + 16 bytes
+constexpr int WG_PB = 128 * 2 + 16;      // LDS row pitch of the dZ tile: 128 channels + 16 bytes
 
-// Eight consecutive reduction rows of one column per lane: two transposing reads (rows
-// 0-3 and 4-7 of the lane group's block, PITCH bytes apart) and the wait for both.
+// Eight consecutive reduction rows of one column per lane for N fragments 32 bytes (16
+// columns) apart: two transposing reads each (rows 0-3 and 4-7 of the lane group's block,
+// 4 * PITCH bytes apart), one wait for all of them.
 template <int PITCH>
-__device__ __forceinline__ uint4 lds_read_tr8(const char *p) {
-    uint2 lo, hi;
+__device__ __forceinline__ void lds_read_tr8x4(const char *p, uint4 (&f)[4]) {
+    uint2 r[8];
     const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\t"
-                 "ds_read_b64_tr_b16 %1, %2 offset:%3\n\t"
+    asm volatile("ds_read_b64_tr_b16 %0, %8\n\t"
+                 "ds_read_b64_tr_b16 %1, %8 offset:%9\n\t"
+                 "ds_read_b64_tr_b16 %2, %8 offset:32\n\t"
+                 "ds_read_b64_tr_b16 %3, %8 offset:%10\n\t"
+                 "ds_read_b64_tr_b16 %4, %8 offset:64\n\t"
+                 "ds_read_b64_tr_b16 %5, %8 offset:%11\n\t"
+                 "ds_read_b64_tr_b16 %6, %8 offset:96\n\t"
+                 "ds_read_b64_tr_b16 %7, %8 offset:%12\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(lo), "=&v"(hi)
-                 : "v"(addr), "n"(4 * PITCH)
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                 : "v"(addr), "n"(4 * PITCH), "n"(4 * PITCH + 32), "n"(4 * PITCH + 64), "n"(4 * PITCH + 96)
                  : "memory");
-    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = make_uint4(r[2 * i].x, r[2 * i].y, r[2 * i + 1].x, r[2 * i + 1].y);
+}
+template <int PITCH>
+__device__ __forceinline__ void lds_read_tr8x2(const char *p, uint4 (&f)[2]) {
+    uint2 r[4];
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                 "ds_read_b64_tr_b16 %1, %4 offset:%5\n\t"
+                 "ds_read_b64_tr_b16 %2, %4 offset:32\n\t"
+                 "ds_read_b64_tr_b16 %3, %4 offset:%6\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+                 : "v"(addr), "n"(4 * PITCH), "n"(4 * PITCH + 32)
+                 : "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) f[i] = make_uint4(r[2 * i].x, r[2 * i].y, r[2 * i + 1].x, r[2 * i + 1].y);
 }
 
+template <int TCI>
 __global__ void __launch_bounds__(256)
 conv_wgrad_kernel(const WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) char sA[64 * WG_PA];
+    constexpr int PA = TCI * 2 + 16;                 // LDS row pitch of the X tile
+    constexpr int WCI = TCI / 64;                    // waves along the input channels
+    constexpr int NJ = 2 * WCI;                      // 16-column blocks of output channels per wave
+    constexpr int NA = TCI / 8 * 64 / 256;           // 16-byte items of the X tile per thread (2 or 4)
+    __shared__ __attribute__((aligned(16))) char sA[64 * PA];
     __shared__ __attribute__((aligned(16))) char sB[64 * WG_PB];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wci = wave % WCI, wco = wave / WCI;
     const int tile_ci = blockIdx.x % a.n_ci_tiles, tile_co = blockIdx.x / a.n_ci_tiles;
     const int tap = blockIdx.y, tr = tap / a.k, tc = tap - tr * a.k;
-    const int ci0 = tile_ci * 64, co0 = tile_co * 128;
-    const long long c_begin = (long long)blockIdx.z * a.chunks_per_split;
-    long long c_end = c_begin + a.chunks_per_split;
-    const long long nchunks = (a.P + 63) / 64;
+    const int ci0 = tile_ci * TCI, co0 = tile_co * 128;
+    const int c_begin = blockIdx.z * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    const int nchunks = (a.P + 63) / 64;
     if (c_end > nchunks) c_end = nchunks;
 
-    f32x4_t acc[4][2];
+    f32x4_t acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // staging geometry: X tile = 64 rows x 8 sixteen-byte items (2 per thread), dZ tile = 64 x 16 (4 per thread)
-    uint4 ra[2], rb[4];
-    auto load_chunk = [&](long long chunk) {
-        const long long p0 = chunk * 64;
+    uint4 ra[NA], rb[4];
+    auto load_chunk = [&](int chunk) {
+        const int p0 = chunk * 64;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = t + u * 256, row = e >> 3, it = e & 7;
-            const long long p = p0 + row;
+        for (int u = 0; u < NA; ++u) {
+            const int e = t + u * 256, row = e / (TCI / 8), it = e % (TCI / 8);
+            const int p = p0 + row;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             const int ci = ci0 + it * 8;
             if (p < a.P && ci < a.Cin) {
-                const int ow = (int)(p % a.OW);
-                const long long q = p / a.OW;
-                const int oh = (int)(q % a.OH), b = (int)(q / a.OH);
+                const int b = fastdiv(p, a.ohw_m, a.ohw_s), rem = p - b * (a.OH * a.OW);
+                const int oh = fastdiv(rem, a.ow_m, a.ow_s), ow = rem - oh * a.OW;
                 const int ih = oh * a.stride + tr - a.pad, iw = ow * a.stride + tc - a.pad;
                 if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
                     v = *(const uint4 *)(a.x + (((size_t)b * a.H + ih) * a.W + iw) * a.x_ld + ci);
@@ -187,7 +292,7 @@ conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = t + u * 256, row = e >> 4, it = e & 15;
-            const long long p = p0 + row;
+            const int p = p0 + row;
             const int co = co0 + it * 8;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (p < a.P && co < a.Cout) v = *(const uint4 *)(a.dz + (size_t)p * a.dz_ld + co);
@@ -196,9 +301,9 @@ conv_wgrad_kernel(const WgradArgs a) {
     };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = t + u * 256, row = e >> 3, it = e & 7;
-            *(uint4 *)(sA + row * WG_PA + it * 16) = ra[u];
+        for (int u = 0; u < NA; ++u) {
+            const int e = t + u * 256, row = e / (TCI / 8), it = e % (TCI / 8);
+            *(uint4 *)(sA + row * PA + it * 16) = ra[u];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -210,30 +315,28 @@ conv_wgrad_kernel(const WgradArgs a) {
     // transposed-read geometry: 16-lane group g covers reduction rows 8 g .. 8 g + 7 of a
     // 32-pixel step; lane 4 q + p of the group addresses row q, columns 4 p .. 4 p + 3
     const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-    const int a_off = (8 * g + q4) * WG_PA + p4 * 8;
-    const int b_off = (8 * g + q4) * WG_PB + (wave * 32) * 2 + p4 * 8;
+    const int a_off = (8 * g + q4) * PA + wci * 128 + p4 * 8;
+    const int b_off = (8 * g + q4) * WG_PB + wco * (NJ * 32) + p4 * 8;
 
     if (c_begin < c_end) load_chunk(c_begin);
-    for (long long chunk = c_begin; chunk < c_end; ++chunk) {
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
         __syncthreads();                       // the previous step's reads are done
         store_chunk();
         __syncthreads();
         if (chunk + 1 < c_end) load_chunk(chunk + 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {       // two 32-pixel reduction steps per chunk
-            uint4 fa[4], fb[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i] = lds_read_tr8<WG_PA>(sA + ks * 32 * WG_PA + a_off + i * 32);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                fb[j] = lds_read_tr8<WG_PB>(sB + ks * 32 * WG_PB + b_off + j * 32);
+            uint4 fa[4], fb[NJ];
+            lds_read_tr8x4<PA>(sA + ks * 32 * PA + a_off, fa);
+            if constexpr (NJ == 4) {
+                lds_read_tr8x4<WG_PB>(sB + ks * 32 * WG_PB + b_off, fb);
+            } else {
+                lds_read_tr8x2<WG_PB>(sB + ks * 32 * WG_PB + b_off, fb);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[i]),
                                                                          __builtin_bit_cast(bf16x8_t, fb[j]), acc[i][j], 0, 0, 0);
         }
@@ -243,18 +346,20 @@ conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ci = ci0 + i * 16 + 4 * (lane >> 4) + r;
-                const int co = co0 + wave * 32 + j * 16 + (lane & 15);
+                const int ci = ci0 + wci * 64 + i * 16 + 4 * (lane >> 4) + r;
+                const int co = co0 + wco * (NJ * 16) + j * 16 + (lane & 15);
                 if (ci < a.Cin && co < a.Cout) out[(size_t)ci * a.Cout + co] = acc[i][j][r];
             }
 }
 
+static int wgrad_tci(int Cin) { return Cin > 64 ? 128 : 64; }
 static int wgrad_splits(int k, int Cin, int Cout, long long P) {
-    const long long base = (long long)((Cin + 63) / 64) * ((Cout + 127) / 128) * k * k;
-    long long splits = (2048 + base - 1) / base;                 // about eight workgroups per CU in all
+    const int tci = wgrad_tci(Cin);
+    const long long base = (long long)((Cin + tci - 1) / tci) * ((Cout + 127) / 128) * k * k;
+    long long splits = (1536 + base - 1) / base;                 // about six workgroups per CU in all
     const long long nchunks = (P + 63) / 64;
     if (splits > nchunks / 4) splits = nchunks / 4;              // at least four chunks per slice
     if (splits > 256) splits = 256;
@@ -275,14 +380,20 @@ int launch_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float 
     a.pad = stride == 1 ? (k - 1) / 2 : 1;                       // stride 2: one zero row / column on the top / left only
     a.x_ld = x_ld > 0 ? x_ld : Cin;
     a.dz_ld = dz_ld > 0 ? dz_ld : Cout;
-    a.P = (long long)B * a.OH * a.OW;
-    const int splits = wgrad_splits(k, Cin, Cout, a.P);
-    const long long nchunks = (a.P + 63) / 64;
+    const long long P = (long long)B * a.OH * a.OW;
+    if (P >= (1LL << 31) - 64) return fail(YMX_EUNSUPPORTED, "conv_wgrad: more than 2^31 output pixels");
+    a.P = (int)P;
+    set_fastdiv((unsigned)a.OW, a.ow_m, a.ow_s);
+    set_fastdiv((unsigned)(a.OH * a.OW), a.ohw_m, a.ohw_s);
+    const int splits = wgrad_splits(k, Cin, Cout, P);
+    const int nchunks = (int)((P + 63) / 64);
     a.chunks_per_split = (nchunks + splits - 1) / splits;
-    a.n_ci_tiles = (Cin + 63) / 64;
+    const int tci = wgrad_tci(Cin);
+    a.n_ci_tiles = (Cin + tci - 1) / tci;
     a.out = splits > 1 ? (float *)ws : dw;
     const int gx = a.n_ci_tiles * ((Cout + 127) / 128);
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, k * k, splits), dim3(256), 0, s, a);
+    if (tci == 128) hipLaunchKernelGGL(conv_wgrad_kernel<128>, dim3(gx, k * k, splits), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<64>, dim3(gx, k * k, splits), dim3(256), 0, s, a);
     int rc = check_launch("conv_wgrad");
     if (rc || splits == 1) return rc;
     const size_t n = (size_t)k * k * Cin * Cout;

@@ -129,16 +129,16 @@ class _ConvBlock(torch.autograd.Function):
             dz = dy
         L = _lib.lib()
         npix = b * oh * ow
-        # bias
-        dbias = None
-        if ctx.needs_input_grad[2]:
-            dbias = torch.empty((cout,), device=x.device, dtype=torch.float32)
-            nb = L.ymx_bias_grad_workspace_bytes(npix, cout)
-            ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)
-            _lib.launch("ymx_bias_grad", dz, _lib.ptr(dz), npix, cout, 0, code, _lib.ptr(dbias), _lib.ptr(ws), nb)
         # channel counts the MFMA kernels take (multiples of 8): zero padding changes nothing
         dzp = _pad_channels(dz)
         coutp = dzp.shape[-1]
+        dbias = None
+        if ctx.needs_input_grad[2]:
+            dbp = torch.empty((coutp,), device=x.device, dtype=torch.float32)
+            nb = L.ymx_bias_grad_workspace_bytes(npix, coutp)
+            ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)
+            _lib.launch("ymx_bias_grad", dzp, _lib.ptr(dzp), npix, coutp, 0, code, _lib.ptr(dbp), _lib.ptr(ws), nb)
+            dbias = dbp[:cout]
         dkernel = None
         if ctx.needs_input_grad[1]:
             xp = _pad_channels(x.to(cdt))
