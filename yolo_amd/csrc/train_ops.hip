@@ -129,6 +129,34 @@ sum_partials_kernel(const float *__restrict__ partial, float *__restrict__ out, 
     }
 }
 
+// The same for short vectors (bias gradients: n = channels) where a thread per element would
+// leave the GPU to a handful of serial loops: 32 elements x 8 part lanes per workgroup, lane l
+// adds parts l, l + 8, ... and the eight lane sums are added in order.
+__global__ void __launch_bounds__(256)
+sum_partials_small_kernel(const float *__restrict__ partial, float *__restrict__ out, int n, int parts) {
+    __shared__ float red[8][32];
+    const int t = threadIdx.x, e = t & 31, pl = t >> 5;
+    const int i = blockIdx.x * 32 + e;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    if (i < n) {
+        int s = pl;
+        for (; s + 24 < parts; s += 32) {
+            const float v0 = partial[(size_t)s * n + i], v1 = partial[(size_t)(s + 8) * n + i];
+            const float v2 = partial[(size_t)(s + 16) * n + i], v3 = partial[(size_t)(s + 24) * n + i];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; s < parts; s += 8) a0 += partial[(size_t)s * n + i];
+    }
+    red[pl][e] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (t < 32 && i < n) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) sum += red[l][t];
+        out[i] = sum;
+    }
+}
+
 // bf16 rows whose 16-byte chunks divide the workgroup (C / 8 a power of two up to 256, dense
 // or padded rows): thread = (row lane, chunk); every thread sums its chunk's eight channels
 // over the slab's rows in steps of 256 / chunks rows, the row lanes are then added in LDS in
@@ -178,7 +206,7 @@ int launch_bias_grad(const void *dz, long long P, int C, int ld, int dtype, floa
     else hipLaunchKernelGGL(colsum_kernel<float>, dim3(parts), dim3(256), 0, s, (const float *)dz, partial, P, C, ld, rows_per);
     int rc = check_launch("bias_grad");
     if (rc) return rc;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, db, (size_t)C, parts);
+    hipLaunchKernelGGL(sum_partials_small_kernel, dim3((C + 31) / 32), dim3(256), 0, s, partial, db, C, parts);
     return check_launch("bias_grad_reduce");
 }
 
