@@ -320,6 +320,154 @@ def cpu_baseline(num_classes, side, budget_s=15.0):
                       (n, batch, side, side, dt)}
 
 
+def train_workload(args, dev, rank, world):
+    """BASELINE config 5: one training step per timed step -- forward with the graph recorded,
+    the YOLO loss at the three scales, back-propagation through every block (input, weight and
+    bias gradients), gradient averaging over the ranks (one bucketed all-reduce, N > 1 only),
+    plain SGD.  Batch = images per GPU (512 / 8 = 64 in the configuration)."""
+    import numpy as np
+    import torch.distributed as dist
+    import yolo_amd as Y
+    from yolo_amd import Detector, dataset as DS, losses as L, training as T
+    from yolo_amd import dist as ydist
+    from yolo_amd.layers import YOLOConv
+    B, S, C = args.batch, args.size, args.classes
+    cfg = Y.config
+    det = Detector(num_classes=C, dtype=torch.bfloat16, seed=0).to(dev)          # same seed: replicated weights
+    cal = torch.rand(2, S, S, 3, generator=torch.Generator(device="cpu").manual_seed(100)).to(dev)
+    det.calibrate_(cal)
+    x = torch.rand(B, S, S, 3, generator=torch.Generator(device="cpu").manual_seed(100 + rank)).to(dev)
+    rng = np.random.default_rng(200 + rank)
+    nmax = 32
+    counts = rng.integers(1, nmax, B).astype(np.int32)
+    boxes = np.zeros((B, nmax, 5), np.float32)
+    for b in range(B):
+        n = counts[b]
+        wh = np.exp(rng.normal(3.5, 1.0, (n, 2))).clip(4, S * 0.9)
+        ctr = rng.uniform(0, S, (n, 2))
+        x0 = np.clip(ctr - wh / 2, 0, S - 2)
+        x1 = np.clip(ctr + wh / 2, x0 + 1, S - 1)
+        boxes[b, :n] = np.floor(np.concatenate([x0, x1, rng.integers(0, C, (n, 1))], 1))
+    targets = DS.pack_targets(*DS.preprocess_true_boxes(torch.from_numpy(boxes).to(dev), torch.from_numpy(counts).to(dev), S, C))
+    fns = L.get_yolo_loss_at_scales([0, 1, 2], C, cfg["strides"], 0.5, cfg["xyscale"], cfg["anchors"])   # scales 2, 1, 0
+    params = list(det.backbone.parameters()) + list(det.head.parameters())
+    buckets = ydist.GradientBuckets(params) if world > 1 else None
+    lr = 1e-7
+    flops = [0.0]
+
+    def count(mod, inp, out):
+        flops[0] += 2.0 * out.shape[0] * out.shape[1] * out.shape[2] * mod.kernel_size ** 2 * mod.in_channels * mod.filters
+
+    def step():
+        with T.backprop():
+            s, m, l = det.head(*det.backbone(x))
+        loss = fns[0](targets[2], l) + fns[1](targets[1], m) + fns[2](targets[0], s)
+        if buckets is None:
+            for p in params:
+                p.grad = None
+        else:
+            buckets.zero_()
+        loss.backward()
+        if buckets is not None:
+            buckets.reduce().wait()
+        with torch.no_grad():
+            torch._foreach_add_(params, [p.grad for p in params], alpha=-lr)
+        return loss
+
+    hooks = [m.register_forward_hook(count) for m in det.modules() if isinstance(m, YOLOConv)]
+    first = float(step().detach())
+    for h in hooks:
+        h.remove()
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    last = float(loss.detach())
+    if rank != 0:
+        return
+    ms = dt / args.steps * 1e3
+    total_flops = 3.0 * flops[0]                     # forward, input gradient, weight gradient
+    result = {
+        "metric": "images/sec (training step: fwd + YOLO loss + bwd + SGD) at %d^2" % S,
+        "value": round(B * world * args.steps / dt, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "training step: Darknet53+YoloV3(C=%d) forward with saved pre-activations, YOLO loss at three scales, "
+                               "backward (dgrad on the forward kernels, MFMA wgrad, bias grad), %sSGD; %dx%d, batch %d per GPU, bf16 "
+                               "storage / fp32 accumulate and fp32 master weights, activation-calibrated random weights"
+                               % (C, "bucketed gradient all-reduce, " if world > 1 else "", S, S, B),
+                   "global_batch": B * world, "per_gpu_batch": B, "image_size": S, "num_classes": C,
+                   "parallelism": "dp%d" % world if world > 1 else "single GPU", "loss_first": round(first, 3), "loss_last": round(last, 3),
+                   "peak_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)},
+        "roofline": {"bound": "mfma", "kernel": "all convolution kernels of the step (forward + input gradient + weight gradient)",
+                     "achieved": round(total_flops / (ms * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(total_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                     "flops_per_step": total_flops, "measured": "whole step, wall clock (elementwise kernels and the loss included in the time)"},
+    }
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline_train(C, S)
+    print(json.dumps(result), flush=True)
+
+
+def cpu_baseline_train(C, side, budget_s=25.0):
+    """The oracle's training step on this host: torch-CPU fp32 forward of the restated network
+    with autograd, the restated loss in float64, backward; batch 1."""
+    import numpy as np
+    from oracle import net_torch as N
+    from oracle import loss_torch as LT
+    from oracle import postproc_np as P
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    bp = N.init_params(N.darknet53_specs(), seed=0, init="reference")
+    hp = N.init_params(N.yolov3_specs(C), seed=1, init="reference")
+    for plist in (bp, hp):
+        for p in plist:
+            for name in ("kernel", "bias"):
+                p[name] = p[name].clone().requires_grad_(True)
+    x = torch.rand(1, side, side, 3, generator=torch.Generator().manual_seed(1))
+    D = 5 + C
+
+    def step():
+        heads = N.detector_forward(bp, hp, x, C)
+        total = 0
+        for i, h in enumerate(heads):
+            Si = h.shape[1]
+            conv5 = h.double().reshape(1, Si, Si, 3, D)
+            label = torch.zeros_like(conv5)
+            label[0, Si // 2, Si // 2, 1] = torch.tensor([side / 2, side / 2, 40.0, 40.0, 1.0] + [0.0] * C, dtype=torch.float64)
+            bboxes = torch.zeros(1, 128, 4, dtype=torch.float64)
+            bboxes[0, 0] = torch.tensor([side / 2, side / 2, 40.0, 40.0], dtype=torch.float64)
+            pred = LT.decode_train(conv5, i, Si, P.STRIDES, P.XYSCALE, P.ANCHORS)
+            g, c, p = LT.yolo_loss(pred, conv5, label, bboxes, side, 0.5)
+            total = total + g + c + p
+        total.backward()
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 8:
+            break
+    return {"value": round(n / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d training steps of batch 1 at %dx%d, fp32 torch-CPU forward + autograd backward, loss in float64 (%.1f s)" % (n, side, side, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -332,9 +480,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--per-op", action="store_true", help="also print the per-launch table to stderr")
-    ap.add_argument("--workload", default="detector", choices=["detector", "nms-stress"],
+    ap.add_argument("--workload", default="detector", choices=["detector", "nms-stress", "train"],
                     help="detector (default): the whole hot path; nms-stress: decode+filter+NMS alone on 100 800 "
-                         "synthetic candidates per image (use --batch 32)")
+                         "synthetic candidates per image (use --batch 32); train: one training step per step "
+                         "(forward, YOLO loss, backward, SGD; gradient all-reduce when --gpus > 1)")
     ap.add_argument("--split", default="auto", help="sub-batches run concurrently on separate streams: "
                     "auto (timed once), off, or sizes such as 48,16")
     args = ap.parse_args()
@@ -365,6 +514,13 @@ def main():
         if args.batch == 64:
             args.batch = 32                          # the configuration's batch unless overridden
         stress_workload(args, dev)
+        return
+    if args.workload == "train":
+        if args.steps == 20:
+            args.steps = 10
+        train_workload(args, dev, rank, world)
+        if world > 1:
+            dist.destroy_process_group()
         return
 
     from yolo_amd import Detector
