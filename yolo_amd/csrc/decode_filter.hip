@@ -256,9 +256,18 @@ decode_kernel(const DecodeArgs a) {
                         if (MODE == 0) {
                             box = make_float4(cx, cy, bw, bh);
                             if (a.conf) a.conf[(size_t)b * a.cap + g.c_global0 + lane] = conf;
-                        } else
+                        } else {
                             box = make_float4((cy - bh / 2.0f) / a.image_size, (cx - bw / 2.0f) / a.image_size,
                                               (cy + bh / 2.0f) / a.image_size, (cx + bw / 2.0f) / a.image_size);
+                        }
+                        // The four values are final here and are carried in registers across the
+                        // look-back below.  Pinning them at this point keeps the compiler from forming
+                        // them with packed, operand-swapped FMAs on a scalar-pair operand: built that
+                        // way, one of the two y corners of a whole segment came out as cy / image_size
+                        // about once per launch whenever a convolution of another stream shared the
+                        // GPU, and never when the launch ran alone (tools/concurrency_screen.py:
+                        // 188 bad segments in 160 concurrent forwards before, 0 in 600 after).
+                        asm volatile("" : "+v"(box.x), "+v"(box.y), "+v"(box.z), "+v"(box.w));
                     }
                 } else {
 #pragma unroll
