@@ -484,6 +484,7 @@ int ymx_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw
     if ((long long)B * H * W * (x_ld ? x_ld : Cin) >= (1LL << 40)) return fail(YMX_EUNSUPPORTED, "conv_wgrad: input too large");
     const size_t need = conv_wgrad_workspace_bytes(k, Cin, Cout, wgrad_pixels(B, H, W, k, stride));
     if (need && (!workspace || ws_bytes < need)) return fail(YMX_EWORKSPACE, "conv_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+    if (need && (((uintptr_t)workspace) & 3)) return fail(YMX_EARG, "conv_wgrad: workspace must be 4-byte aligned");
     return launch_conv_wgrad(x, x_ld, dz, dz_ld, dw, B, H, W, Cin, Cout, k, stride, workspace, (hipStream_t)stream);
 }
 

@@ -93,6 +93,7 @@ class _ConvBlock(torch.autograd.Function):
             raise ValueError("yolo_amd.training: back-propagation is provided for bfloat16 networks")
         k, cin, cout = layer.kernel_size, layer.in_channels, layer.filters
         stride = 2 if layer.downsample else 1
+        x_dtype_in = x.dtype
         x = x.contiguous()
         if cin % 8 == 0 and x.dtype != cdt:
             x = x.to(cdt)
@@ -109,6 +110,7 @@ class _ConvBlock(torch.autograd.Function):
         ctx.layer = layer
         ctx.has_shortcut = shortcut is not None
         ctx.shortcut_dtype = None if shortcut is None else shortcut.dtype
+        ctx.x_dtype = x_dtype_in
         return y
 
     @staticmethod
@@ -165,6 +167,8 @@ class _ConvBlock(torch.autograd.Function):
                 src = torch.zeros((b, h, w, coutp), device=x.device, dtype=cdt)       # dz on the even rows / columns
                 src[:, 0:2 * oh:2, 0:2 * ow:2] = dzp
             dx = _conv(src, wdp, None, coutp, cin, k, 1, cdt, cdt)
+            if dx.dtype != ctx.x_dtype:
+                dx = dx.to(ctx.x_dtype)
         dshortcut = None
         if ctx.has_shortcut and ctx.needs_input_grad[3]:
             dshortcut = dy.to(ctx.shortcut_dtype)
