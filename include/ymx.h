@@ -311,6 +311,11 @@ int ymx_yolo_loss_grad(const float *conv, int conv_ld, const float *label, long 
  * elements, 0 = dense. */
 int ymx_act_apply(const void *z, const void *residual, void *y, long long n, int act, int dtype, void *stream);
 int ymx_act_backward(const void *z, const void *dy, void *dz, long long n, int act, int dtype, void *stream);
+/* ymx_act_backward and ymx_bias_grad in one pass over dense [n_pix, C] rows (bf16, act 1 or 2,
+ * C / 8 a power of two up to 256; ..._workspace_bytes returns 0 for anything else). */
+size_t ymx_act_backward_bias_workspace_bytes(long long n_pix, int C, int act, int dtype);
+int ymx_act_backward_bias(const void *z, const void *dy, void *dz, long long n_pix, int C, int act, int dtype,
+                          float *db, void *workspace, size_t ws_bytes, void *stream);
 size_t ymx_bias_grad_workspace_bytes(long long n_pix, int C);
 int ymx_bias_grad(const void *dz, long long n_pix, int C, int ld, int dtype, float *db,
                   void *workspace, size_t ws_bytes, void *stream);

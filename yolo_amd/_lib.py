@@ -61,6 +61,8 @@ SIGNATURES = {
                                 _vp, _vp, _vp]),
     "ymx_act_apply": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp]),
     "ymx_act_backward": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp]),
+    "ymx_act_backward_bias_workspace_bytes": (_sz, [ctypes.c_longlong, _i, _i, _i]),
+    "ymx_act_backward_bias": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ymx_bias_grad_workspace_bytes": (_sz, [ctypes.c_longlong, _i]),
     "ymx_bias_grad": (_i, [_vp, ctypes.c_longlong, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ymx_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),

@@ -450,6 +450,21 @@ int ymx_act_backward(const void *z, const void *dy, void *dz, long long n, int a
     return launch_act(z, dy, dz, (size_t)n, act, dtype, 1, (hipStream_t)stream);
 }
 
+size_t ymx_act_backward_bias_workspace_bytes(long long n_pix, int C, int act, int dtype) {
+    return act_bwd_bias_supported(n_pix, C, act, dtype) ? act_bwd_bias_workspace_bytes(n_pix, C) : 0;
+}
+
+int ymx_act_backward_bias(const void *z, const void *dy, void *dz, long long n_pix, int C, int act, int dtype, float *db,
+                          void *workspace, size_t ws_bytes, void *stream) {
+    if (!z || !dy || !dz || !db) return fail(YMX_EARG, "act_backward_bias: null pointer");
+    if (!act_bwd_bias_supported(n_pix, C, act, dtype))
+        return fail(YMX_EUNSUPPORTED, "act_backward_bias: bf16, leaky or mish, and a power-of-two number (<= 256) of 8-channel chunks per row are required (C = %d)", C);
+    if (!aligned16(z) || !aligned16(dy) || !aligned16(dz)) return fail(YMX_EARG, "act_backward_bias: 16-byte alignment");
+    const size_t need = act_bwd_bias_workspace_bytes(n_pix, C);
+    if (!workspace || ws_bytes < need || (((uintptr_t)workspace) & 3)) return fail(YMX_EWORKSPACE, "act_backward_bias: workspace %zu < %zu bytes", ws_bytes, need);
+    return launch_act_bwd_bias(z, dy, dz, n_pix, C, act, db, workspace, (hipStream_t)stream);
+}
+
 size_t ymx_bias_grad_workspace_bytes(long long n_pix, int C) { return (n_pix > 0 && C > 0) ? bias_grad_workspace_bytes(n_pix, C) : 0; }
 
 int ymx_bias_grad(const void *dz, long long n_pix, int C, int ld, int dtype, float *db, void *workspace, size_t ws_bytes, void *stream) {

@@ -228,6 +228,9 @@ int launch_draw_boxes(unsigned char *img, int B, int H, int W, const float *boxe
                       const unsigned char *colors, int C, int thick, hipStream_t s);
 int launch_act(const void *z, const void *other, void *y, size_t n, int act, int dtype, int mode, hipStream_t s);
 size_t bias_grad_workspace_bytes(long long P, int C);
+bool act_bwd_bias_supported(long long P, int C, int act, int dtype);
+size_t act_bwd_bias_workspace_bytes(long long P, int C);
+int launch_act_bwd_bias(const void *z, const void *dy, void *dz, long long P, int C, int act, float *db, void *ws, hipStream_t s);
 int launch_bias_grad(const void *dz, long long P, int C, int ld, int dtype, float *db, void *ws, hipStream_t s);
 size_t conv_wgrad_workspace_bytes(int k, int Cin, int Cout, long long P);
 int launch_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw, int B, int H, int W, int Cin, int Cout, int k,

@@ -210,6 +210,66 @@ int launch_bias_grad(const void *dz, long long P, int C, int ld, int dtype, floa
     return check_launch("bias_grad_reduce");
 }
 
+// dz = dy * act'(z) and the column sums of dz in one pass (bf16, C / 8 a power of two up to
+// 256, dense rows): a thread keeps the same 16-byte channel chunk for its whole strided walk
+// (256 is a multiple of the chunks per row), so it carries eight running sums; the workgroup
+// then adds its row lanes in LDS in a fixed order and writes one partial row, and
+// sum_partials_small_kernel adds the workgroups' rows in order.  The sums are taken over the
+// bf16-rounded dz, the values the weight gradient reads.
+__global__ void __launch_bounds__(256)
+act_bwd_bias_kernel(const uint4 *__restrict__ z, const uint4 *__restrict__ dy, uint4 *__restrict__ dz, float *__restrict__ partial,
+                    size_t n8, int C, int act) {
+    __shared__ float red[256 * 8];
+    const int nch = C >> 3, t = threadIdx.x;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + t; i < n8; i += (size_t)gridDim.x * 256) {
+        const uint4 zv = z[i], ov = dy[i];
+        const uint32_t zw[4] = {zv.x, zv.y, zv.z, zv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
+        uint32_t r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float z0 = __uint_as_float(zw[k] << 16), z1 = __uint_as_float(zw[k] & 0xffff0000u);
+            const float o0 = __uint_as_float(ow[k] << 16), o1 = __uint_as_float(ow[k] & 0xffff0000u);
+            const float a0 = o0 * (act == 2 ? mish_grad_f(z0) : (z0 > 0.0f ? 1.0f : 0.1f));
+            const float a1 = o1 * (act == 2 ? mish_grad_f(z1) : (z1 > 0.0f ? 1.0f : 0.1f));
+            r[k] = pack2_bf16(a0, a1);
+            acc[2 * k] += __uint_as_float(r[k] << 16);
+            acc[2 * k + 1] += __uint_as_float(r[k] & 0xffff0000u);
+        }
+        dz[i] = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[t * 8 + k] = acc[k];
+    __syncthreads();
+    const int nrl = 256 / nch;
+    for (int c = t; c < C; c += 256) {
+        const int cch = c >> 3, k = c & 7;
+        float sum = 0.0f;
+        for (int l = 0; l < nrl; ++l) sum += red[(l * nch + cch) * 8 + k];
+        partial[(size_t)blockIdx.x * C + c] = sum;
+    }
+}
+
+static int act_bwd_bias_parts(size_t n8) {
+    const size_t g = (n8 + 255) / 256;
+    return (int)(g > 1024 ? 1024 : (g < 1 ? 1 : g));
+}
+bool act_bwd_bias_supported(long long P, int C, int act, int dtype) {
+    const int nch = C / 8;
+    return dtype == YMX_BF16 && (act == 1 || act == 2) && C % 8 == 0 && nch >= 1 && nch <= 256 && (nch & (nch - 1)) == 0 && P > 0;
+}
+size_t act_bwd_bias_workspace_bytes(long long P, int C) { return (size_t)act_bwd_bias_parts((size_t)P * C / 8) * C * 4; }
+
+int launch_act_bwd_bias(const void *z, const void *dy, void *dz, long long P, int C, int act, float *db, void *ws, hipStream_t s) {
+    const size_t n8 = (size_t)P * C / 8;
+    const int parts = act_bwd_bias_parts(n8);
+    hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(parts), dim3(256), 0, s, (const uint4 *)z, (const uint4 *)dy, (uint4 *)dz, (float *)ws, n8, C, act);
+    int rc = check_launch("act_backward_bias");
+    if (rc) return rc;
+    hipLaunchKernelGGL(sum_partials_small_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const float *)ws, db, C, parts);
+    return check_launch("act_backward_bias_reduce");
+}
+
 // ---- weight gradient --------------------------------------------------------------------------
 // GEMM  dW[ci][co] (per tap) = sum_p X[p + tap][ci] * dZ[p][co]: both operands have the
 // reduction index (pixels) as their SLOW axis in memory, the opposite of what an MFMA lane

@@ -124,18 +124,25 @@ class _ConvBlock(torch.autograd.Function):
         b, h, w, _ = x.shape
         oh, ow = z.shape[1], z.shape[2]
         dy = dy.to(cdt).contiguous()
-        if layer.act_code != _lib.ACT_NONE:
-            dz = torch.empty_like(z)
-            _lib.launch("ymx_act_backward", z, _lib.ptr(z), _lib.ptr(dy), _lib.ptr(dz), z.numel(), layer.act_code, code)
-        else:
-            dz = dy
         L = _lib.lib()
         npix = b * oh * ow
+        dbias = None
+        if layer.act_code != _lib.ACT_NONE:
+            dz = torch.empty_like(z)
+            nb = L.ymx_act_backward_bias_workspace_bytes(npix, cout, layer.act_code, code) if ctx.needs_input_grad[2] else 0
+            if nb:                       # derivative of the activation and the bias gradient in one pass
+                dbias = torch.empty((cout,), device=x.device, dtype=torch.float32)
+                ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)
+                _lib.launch("ymx_act_backward_bias", z, _lib.ptr(z), _lib.ptr(dy), _lib.ptr(dz), npix, cout, layer.act_code, code,
+                            _lib.ptr(dbias), _lib.ptr(ws), nb)
+            else:
+                _lib.launch("ymx_act_backward", z, _lib.ptr(z), _lib.ptr(dy), _lib.ptr(dz), z.numel(), layer.act_code, code)
+        else:
+            dz = dy
         # channel counts the MFMA kernels take (multiples of 8): zero padding changes nothing
         dzp = _pad_channels(dz)
         coutp = dzp.shape[-1]
-        dbias = None
-        if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[2] and dbias is None:
             dbp = torch.empty((coutp,), device=x.device, dtype=torch.float32)
             nb = L.ymx_bias_grad_workspace_bytes(npix, coutp)
             ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)
