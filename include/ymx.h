@@ -57,8 +57,11 @@ const char *ymx_last_error(void);
  * (2, the default: with the input-resident kernel for 3x3 stride 1 and 32 or 64 input
  * channels; 1: without it) or on the register-staged kernel (0).  "halo_pixels": pixels per
  * tile of the resident-slab 3x3 kernel (0, the default: 192 where that shortens the launch,
- * else 256; 192 or 256 force one).  All kernels add the K
- * terms in the same order: results do not depend on these options. */
+ * else 256; 192 or 256 force one; rows longer than 59 pixels always take 192).
+ * "wgrad_variant": ymx_conv_wgrad on the LDS-DMA kernel where x and dz are under 2 GB (0, the
+ * default) or on the register-staged kernel (1).  All forward kernels add the K terms in the
+ * same order: forward results do not depend on these options (the two weight-gradient kernels
+ * slice the pixel sum differently and agree to fp32 rounding). */
 int ymx_set_option(const char *name, long long value);
 
 /* ---- convolution block ------------------------------------------------------

@@ -66,6 +66,20 @@ def test_conv_block_gradients(case):
     print("conv block gradient errors (of each tensor's scale):", errs)
     for name, e in errs.items():
         assert e < 1e-2, (name, e)
+    # the register-staged weight-gradient kernel (taken for tensors beyond the LDS-DMA kernel's 2 GB
+    # addressing range) gives the same gradient
+    from yolo_amd import _lib
+    g_dma = layer.kernel.grad.clone()
+    layer.kernel.grad = None
+    try:
+        _lib.check(_lib.lib().ymx_set_option(b"wgrad_variant", 1))
+        with T.backprop():
+            y2 = layer(xg.detach(), residual=None if scg is None else scg.detach())
+        (y2.float() * G.to(DEV)).sum().backward()
+    finally:
+        _lib.check(_lib.lib().ymx_set_option(b"wgrad_variant", 0))
+    assert _scaled_err(layer.kernel.grad.cpu(), po["kernel"].grad) < 1e-2
+    assert _scaled_err(layer.kernel.grad.cpu(), g_dma.cpu()) < 1e-5          # same products, another summation order
     # outside the context nothing is recorded and the fused inference kernels run
     y_inf = layer(xg.detach(), residual=None if scg is None else scg.detach())
     assert not y_inf.requires_grad

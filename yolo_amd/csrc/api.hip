@@ -210,6 +210,11 @@ int ymx_set_option(const char *name, long long value) {
         g_halo_pixels = (int)value;
         return YMX_OK;
     }
+    if (!strcmp(name, "wgrad_variant")) {
+        if (value != 0 && value != 1) return fail(YMX_EARG, "set_option: wgrad_variant must be 0 (LDS-DMA where it applies) or 1 (register-staged)");
+        g_wgrad_variant = (int)value;
+        return YMX_OK;
+    }
     if (!strcmp(name, "dma_narrow")) {
         if (value < 0 || value > 2) return fail(YMX_EARG, "set_option: dma_narrow must be 0, 1 or 2");
         t_opt.narrow = value;

@@ -443,18 +443,216 @@ conv_wgrad_kernel(const WgradArgs a) {
             }
 }
 
-static int wgrad_tci(int Cin) { return Cin > 64 ? 128 : 64; }
-static int wgrad_splits(int k, int Cin, int Cout, long long P) {
-    const int tci = wgrad_tci(Cin);
+// ---- weight gradient, LDS-DMA form ----------------------------------------------------------
+// The same GEMM with the tiles brought into LDS by LDS-DMA (no staging registers, no ds_write)
+// and a larger tile for wide layers: TCI = 256 input channels x 128 output channels, waves 2 x 2
+// of 128 x 64 (three LDS bytes read per four MFMA results instead of four).  A step is 32
+// pixels; a ring of three or four buffers, the transfers of the next two or three steps are in
+// flight under the current step's MFMAs (counted vmcnt: they complete in order), one barrier per
+// step.  LDS rows are unpadded ([pixel][channel], as the DMA writes them: lane l
+// of an instruction fills bytes 16 l .. 16 l + 15); bank conflicts of the transposing reads are
+// avoided by permuting the 32-byte column groups of a row with an XOR of row bits, applied on
+// the SOURCE side of the DMA and undone in the read addresses.  Rows outside the image (a
+// shifted tap at the border, the tail of the last step, channels beyond Cin / Cout) are
+// out-of-range buffer offsets, which the hardware fills with zeros.
+template <int TCI> struct WgradGeom {
+    static constexpr int WCI = TCI >= 128 ? 2 : 1;     // waves along the input channels
+    static constexpr int WCO = 4 / WCI;
+    static constexpr int NI = TCI / (16 * WCI);        // 16-row blocks of input channels per wave
+    static constexpr int NJ = 128 / (16 * WCO);        // 16-column blocks of output channels per wave
+    static constexpr int RA = TCI * 2, RB = 256;       // LDS row bytes
+    static constexpr int A_BYTES = 32 * RA, B_BYTES = 32 * RB;
+    static constexpr int A_INSTR = A_BYTES / 1024, B_INSTR = B_BYTES / 1024;
+    static constexpr int BUF = A_BYTES + B_BYTES;
+    // ring stages: what one CU must keep in flight to cover the latency of its loads is about
+    // 100 KB, so the ring is as deep as LDS allows at two (TCI = 256) or more workgroups per CU
+    static constexpr int NS = TCI == 256 ? 3 : 4;
+    static constexpr int PER_WAVE = (A_INSTR + B_INSTR) / 4;   // DMA instructions per wave and step
+    static constexpr int LDS_BYTES = NS * BUF;
+};
+
+__device__ __forceinline__ int wg_rowmix(int r) { return (r & 3) | ((r >> 1) & 4); }
+
+// two transposing reads per address (rows r and r + 4 of the lane group's block), four addresses
+template <int ROWB>
+__device__ __forceinline__ void lds_read_tr8_addr4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, uint4 *f) {
+    uint2 r[8];
+    asm volatile("ds_read_b64_tr_b16 %0, %8\n\t"
+                 "ds_read_b64_tr_b16 %1, %8 offset:%12\n\t"
+                 "ds_read_b64_tr_b16 %2, %9\n\t"
+                 "ds_read_b64_tr_b16 %3, %9 offset:%12\n\t"
+                 "ds_read_b64_tr_b16 %4, %10\n\t"
+                 "ds_read_b64_tr_b16 %5, %10 offset:%12\n\t"
+                 "ds_read_b64_tr_b16 %6, %11\n\t"
+                 "ds_read_b64_tr_b16 %7, %11 offset:%12\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(4 * ROWB)
+                 : "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = make_uint4(r[2 * i].x, r[2 * i].y, r[2 * i + 1].x, r[2 * i + 1].y);
+}
+template <int ROWB>
+__device__ __forceinline__ void lds_read_tr8_addr2(unsigned a0, unsigned a1, uint4 *f) {
+    uint2 r[4];
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                 "ds_read_b64_tr_b16 %1, %4 offset:%6\n\t"
+                 "ds_read_b64_tr_b16 %2, %5\n\t"
+                 "ds_read_b64_tr_b16 %3, %5 offset:%6\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+                 : "v"(a0), "v"(a1), "n"(4 * ROWB)
+                 : "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) f[i] = make_uint4(r[2 * i].x, r[2 * i].y, r[2 * i + 1].x, r[2 * i + 1].y);
+}
+
+template <int TCI>
+__global__ void __launch_bounds__(256)
+conv_wgrad_dma_kernel(const WgradArgs a, const unsigned x_bytes, const unsigned dz_bytes) {
+    typedef WgradGeom<TCI> G;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wci = wave % G::WCI, wco = wave / G::WCI;
+    const int tile_ci = blockIdx.x % a.n_ci_tiles, tile_co = blockIdx.x / a.n_ci_tiles;
+    const int tap = blockIdx.y, tr = tap / a.k, tc = tap - tr * a.k;
+    const int ci0 = tile_ci * TCI, co0 = tile_co * 128;
+    const int c_begin = blockIdx.z * a.chunks_per_split;        // steps of 32 pixels
+    int c_end = c_begin + a.chunks_per_split;
+    const int nsteps = (a.P + 31) / 32;
+    if (c_end > nsteps) c_end = nsteps;
+    const i32x4_t xrsrc = make_rsrc(a.x, x_bytes);
+    const i32x4_t zrsrc = make_rsrc(a.dz, dz_bytes);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+
+    // DMA geometry.  X tile: instruction j covers rows [j * RPA, (j + 1) * RPA) of the step,
+    // lane l fills slot l % SA of row l / SA with the data of the un-permuted slot.
+    constexpr int SA = G::RA / 16, RPA = 1024 / G::RA;           // 16-byte slots per row, rows per instruction
+    constexpr int AJ = G::A_INSTR / 4 > 0 ? G::A_INSTR / 4 : 1;  // X instructions per wave (TCI = 64: waves 0-3 take one each)
+    const int a_rl = lane / SA, a_sl = lane % SA;
+    constexpr int BJ = G::B_INSTR / 4;                           // dZ instructions per wave (2)
+    const int b_rl = lane >> 4, b_sl = lane & 15;
+
+    auto issue = [&](int step, int buf) {
+        const int p0 = step * 32;
+        const unsigned base = lds0 + (unsigned)(buf * G::BUF);
+#pragma unroll
+        for (int jj = 0; jj < AJ; ++jj) {
+            const int j = wave + 4 * jj;
+            if (G::A_INSTR < 4 && j >= G::A_INSTR) break;
+            const int row = j * RPA + a_rl;
+            const int p = p0 + row;
+            const int pair = (a_sl >> 1) ^ (wg_rowmix(row) & (SA / 2 - 1));
+            const int ci = ci0 + (pair * 2 + (a_sl & 1)) * 8;
+            unsigned off = OOB;
+            if (p < a.P && ci < a.Cin && step < c_end) {
+                const int b = fastdiv(p, a.ohw_m, a.ohw_s), rem = p - b * (a.OH * a.OW);
+                const int oh = fastdiv(rem, a.ow_m, a.ow_s), ow = rem - oh * a.OW;
+                const int ih = oh * a.stride + tr - a.pad, iw = ow * a.stride + tc - a.pad;
+                if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+                    off = (unsigned)((((b * a.H + ih) * a.W + iw) * a.x_ld + ci) * 2);
+            }
+            lds_dma16(xrsrc, base + (unsigned)(j * 1024), off);
+        }
+#pragma unroll
+        for (int jj = 0; jj < BJ; ++jj) {
+            const int j = wave + 4 * jj;
+            const int row = j * 4 + b_rl;
+            const int p = p0 + row;
+            const int pair = (b_sl >> 1) ^ wg_rowmix(row);
+            const int co = co0 + (pair * 2 + (b_sl & 1)) * 8;
+            unsigned off = OOB;
+            if (p < a.P && co < a.Cout && step < c_end) off = (unsigned)((p * a.dz_ld + co) * 2);
+            lds_dma16(zrsrc, base + (unsigned)(G::A_BYTES + j * 1024), off);
+        }
+    };
+
+    f32x4_t acc[G::NI][G::NJ];
+#pragma unroll
+    for (int i = 0; i < G::NI; ++i)
+#pragma unroll
+        for (int j = 0; j < G::NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read addresses: 16-lane group g covers rows 8 g .. 8 g + 7 of the step; lane
+    // 4 q + p of the group addresses row 8 g + q (and + 4), bytes 8 p .. 8 p + 7 of a block's 32
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int r0 = 8 * g + q4;
+    const int mix = wg_rowmix(r0);                               // the same for row r0 + 4
+    unsigned aoff[G::NI], boff[G::NJ];
+#pragma unroll
+    for (int i = 0; i < G::NI; ++i)
+        aoff[i] = (unsigned)(r0 * G::RA + (((wci * G::NI + i) ^ (mix & (SA / 2 - 1))) * 32) + p4 * 8);
+#pragma unroll
+    for (int j = 0; j < G::NJ; ++j)
+        boff[j] = (unsigned)(G::A_BYTES + r0 * G::RB + (((wco * G::NJ + j) ^ mix) * 32) + p4 * 8);
+
+    // prologue: NS - 1 steps in flight (past the end of the slice the transfers move zeros, which
+    // keeps every wave's instruction count per step the same: the counted waits rely on it)
+#pragma unroll
+    for (int i = 0; i < G::NS - 1; ++i) issue(c_begin + i, i);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G::NS - 2) * G::PER_WAVE) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;
+    for (int step = c_begin; step < c_end; ++step) {
+        {
+            int nb = buf + G::NS - 1;
+            nb = nb >= G::NS ? nb - G::NS : nb;
+            issue(step + G::NS - 1, nb);                         // into the buffer read in the previous iteration
+        }
+        const unsigned base = lds0 + (unsigned)(buf * G::BUF);
+        uint4 fa[G::NI], fb[G::NJ];
+#pragma unroll
+        for (int i = 0; i < G::NI; i += 4)
+            lds_read_tr8_addr4<G::RA>(base + aoff[i], base + aoff[i + 1], base + aoff[i + 2], base + aoff[i + 3], fa + i);
+        if constexpr (G::NJ == 4) lds_read_tr8_addr4<G::RB>(base + boff[0], base + boff[1], base + boff[2], base + boff[3], fb);
+        else lds_read_tr8_addr2<G::RB>(base + boff[0], base + boff[1], fb);
+#pragma unroll
+        for (int i = 0; i < G::NI; ++i)
+#pragma unroll
+            for (int j = 0; j < G::NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[i]),
+                                                                     __builtin_bit_cast(bf16x8_t, fb[j]), acc[i][j], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G::NS - 2) * G::PER_WAVE) : "memory");   // this wave's part of the next step has landed
+        __builtin_amdgcn_s_barrier();                            // everyone's has, and everyone is done reading this buffer
+        asm volatile("" ::: "memory");
+        buf = buf + 1 == G::NS ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float *out = a.out + ((size_t)blockIdx.z * a.k * a.k + tap) * a.Cin * a.Cout;
+#pragma unroll
+    for (int i = 0; i < G::NI; ++i)
+#pragma unroll
+        for (int j = 0; j < G::NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + wci * (G::NI * 16) + i * 16 + 4 * (lane >> 4) + r;
+                const int co = co0 + wco * (G::NJ * 16) + j * 16 + (lane & 15);
+                if (ci < a.Cin && co < a.Cout) out[(size_t)ci * a.Cout + co] = acc[i][j][r];
+            }
+}
+
+thread_local int g_wgrad_variant = 0;        // 0: LDS-DMA kernel where it applies; 1: register-staged kernel (tuning option "wgrad_variant")
+
+static int wgrad_tci(int Cin, bool dma) { return dma ? (Cin > 128 ? 256 : (Cin > 64 ? 128 : 64)) : (Cin > 64 ? 128 : 64); }
+static bool wgrad_use_dma(long long x_bytes, long long dz_bytes) {
+    return g_wgrad_variant != 1 && x_bytes < 0x7fffffffLL && dz_bytes < 0x7fffffffLL;
+}
+static int wgrad_splits(int k, int Cin, int Cout, long long P, bool dma) {
+    const int tci = wgrad_tci(Cin, dma);
     const long long base = (long long)((Cin + tci - 1) / tci) * ((Cout + 127) / 128) * k * k;
-    long long splits = (1536 + base - 1) / base;                 // about six workgroups per CU in all
+    long long splits = ((dma ? 1024 : 1536) + base - 1) / base;  // four / six workgroups per CU in all
     const long long nchunks = (P + 63) / 64;
-    if (splits > nchunks / 4) splits = nchunks / 4;              // at least four chunks per slice
+    if (splits > nchunks / 4) splits = nchunks / 4;              // at least 256 pixels per slice
     if (splits > 256) splits = 256;
     return (int)(splits < 1 ? 1 : splits);
 }
+static long long wgrad_bytes(long long pixels, int ld) { return pixels * ld * 2; }
 size_t conv_wgrad_workspace_bytes(int k, int Cin, int Cout, long long P) {
-    const int splits = wgrad_splits(k, Cin, Cout, P);
+    // the larger of the two kernels' needs (which one runs depends on the tensors' sizes and the option)
+    const int s0 = wgrad_splits(k, Cin, Cout, P, false), s1 = wgrad_splits(k, Cin, Cout, P, true);
+    const int splits = s0 > s1 ? s0 : s1;
     return splits > 1 ? (size_t)splits * k * k * Cin * Cout * 4 : 0;
 }
 
@@ -473,15 +671,33 @@ int launch_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float 
     a.P = (int)P;
     set_fastdiv((unsigned)a.OW, a.ow_m, a.ow_s);
     set_fastdiv((unsigned)(a.OH * a.OW), a.ohw_m, a.ohw_s);
-    const int splits = wgrad_splits(k, Cin, Cout, P);
-    const int nchunks = (int)((P + 63) / 64);
-    a.chunks_per_split = (nchunks + splits - 1) / splits;
-    const int tci = wgrad_tci(Cin);
+    const long long xb = wgrad_bytes((long long)B * H * W, a.x_ld), zb = wgrad_bytes(P, a.dz_ld);
+    const bool dma = wgrad_use_dma(xb, zb);
+    const int splits = wgrad_splits(k, Cin, Cout, P, dma);
+    const int tci = wgrad_tci(Cin, dma);
     a.n_ci_tiles = (Cin + tci - 1) / tci;
     a.out = splits > 1 ? (float *)ws : dw;
     const int gx = a.n_ci_tiles * ((Cout + 127) / 128);
-    if (tci == 128) hipLaunchKernelGGL(conv_wgrad_kernel<128>, dim3(gx, k * k, splits), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<64>, dim3(gx, k * k, splits), dim3(256), 0, s, a);
+    if (dma) {
+        const int nsteps = (int)((P + 31) / 32);
+        a.chunks_per_split = (nsteps + splits - 1) / splits;
+#define YMX_WGRAD_DMA(T)                                                                                                  \
+        {                                                                                                                     \
+            auto kern = conv_wgrad_dma_kernel<T>;                                                                             \
+            static LdsReserve reserved;                                                                                       \
+            if (const int rc = reserve_lds(reserved, (const void *)kern, WgradGeom<T>::LDS_BYTES, "conv_wgrad")) return rc;    \
+            hipLaunchKernelGGL(kern, dim3(gx, k * k, splits), dim3(256), WgradGeom<T>::LDS_BYTES, s, a, (unsigned)xb, (unsigned)zb); \
+        }
+        if (tci == 256) YMX_WGRAD_DMA(256)
+        else if (tci == 128) YMX_WGRAD_DMA(128)
+        else YMX_WGRAD_DMA(64)
+#undef YMX_WGRAD_DMA
+    } else {
+        const int nchunks = (int)((P + 63) / 64);
+        a.chunks_per_split = (nchunks + splits - 1) / splits;
+        if (tci == 128) hipLaunchKernelGGL(conv_wgrad_kernel<128>, dim3(gx, k * k, splits), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(conv_wgrad_kernel<64>, dim3(gx, k * k, splits), dim3(256), 0, s, a);
+    }
     int rc = check_launch("conv_wgrad");
     if (rc || splits == 1) return rc;
     const size_t n = (size_t)k * k * Cin * Cout;
