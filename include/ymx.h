@@ -58,9 +58,11 @@ const char *ymx_last_error(void);
  * channels; 1: without it) or on the register-staged kernel (0).  "halo_pixels": pixels per
  * tile of the resident-slab 3x3 kernel (0, the default: 192 where that shortens the launch,
  * else 256; 192 or 256 force one; rows longer than 59 pixels always take 192).
- * "wgrad_variant": ymx_conv_wgrad on the LDS-DMA kernel where x and dz are under 2 GB (0, the
- * default) or on the register-staged kernel (1).  All forward kernels add the K terms in the
- * same order: forward results do not depend on these options (the two weight-gradient kernels
+ * "wgrad_variant": 0 (the default) lets ymx_conv_wgrad choose: the all-taps LDS-DMA kernel for
+ * 3x3 stride 1 on rows up to 459 pixels, else the per-tap LDS-DMA kernel, both for x and dz
+ * under 2 GB, else the register-staged kernel; 1 forces the register-staged kernel, 2 the
+ * per-tap LDS-DMA kernel (where the tensors allow it).  All forward kernels add the K terms in
+ * the same order: forward results do not depend on these options (the weight-gradient kernels
  * slice the pixel sum differently and agree to fp32 rounding). */
 int ymx_set_option(const char *name, long long value);
 
@@ -306,7 +308,8 @@ int ymx_yolo_loss_grad(const float *conv, int conv_ld, const float *label, long 
  *                                          bf16 x and dz, channel counts multiples of 8; MFMA
  *                                          with transposing LDS reads; pixel slices summed in order)
  *   dx = conv(dz, kernel flipped in r,s and transposed in ci,co), for stride 2 on dz spread
- *        over a zero map of the input's size (even rows / columns): the forward entry points
+ *        over a zero map of the input's size (even rows / columns): the forward entry points,
+ *        with the kernel packed by ymx_pack_weights_dgrad (below)
  *   d residual = dy
  * ymx_upsample2x_backward is the adjoint of ymx_upsample2x_concat's resize half: dx [B,H,W,C]
  * from channels [c_off, c_off + C) of dy [B,2H,2W,dy_ld] (the skip half's gradient is the
@@ -327,6 +330,13 @@ int ymx_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw
                    int Cin, int Cout, int k, int stride, void *workspace, size_t ws_bytes, void *stream);
 int ymx_upsample2x_backward(const void *dy, void *dx, int B, int H, int W, int C, int dy_ld, int c_off,
                             int dtype, void *stream);
+/* Packs, straight from the forward HWIO fp32 kernel [k][k][Cin][Cout], the kernel of the
+ * input-gradient convolution: taps flipped, channel axes swapped, dz_channels (>= Cout, the
+ * channel count dz is stored with; a multiple of 8) input channels of which those beyond Cout
+ * are zero, Cin output channels.  w_packed has ymx_packed_weight_bytes(k, dz_channels, Cin,
+ * dtype) bytes and feeds ymx_conv2d_fused(_ex) with Cin = dz_channels, Cout = Cin. */
+int ymx_pack_weights_dgrad(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dz_channels,
+                           int dtype, void *stream);
 
 /* ---- letterbox resize ---------------------------------------------------------
  * Replaces the image half of image_preprocess (utils.py:16-26): the image is resized by

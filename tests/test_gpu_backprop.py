@@ -24,6 +24,11 @@ CASES = [   # B, H, W, Cin, Cout, k, downsample, act, shortcut
     (2, 9, 7, 16, 24, 3, False, "mish", True),            # partial tiles everywhere
     (1, 40, 40, 64, 192, 3, False, "leaky", True),        # several pixel slices
     (2, 15, 15, 64, 32, 3, True, "mish", False),          # stride 2 on an odd size: 15 -> 7
+    (2, 52, 52, 64, 128, 3, False, "mish", False),        # all-taps weight gradient: many pixel slices, 256-row ring
+    (1, 104, 104, 32, 72, 3, False, "leaky", False),      # 512-row ring, partial channel tiles
+    (1, 13, 13, 256, 512, 3, False, "leaky", False),      # a slice shorter than the ring's run-in
+    (1, 208, 208, 8, 16, 3, False, "leaky", False),       # 1024-row ring (one workgroup per CU)
+    (1, 500, 500, 8, 16, 3, False, "leaky", False),       # too wide for the ring: per-tap kernel
 ]
 
 
@@ -66,20 +71,22 @@ def test_conv_block_gradients(case):
     print("conv block gradient errors (of each tensor's scale):", errs)
     for name, e in errs.items():
         assert e < 1e-2, (name, e)
-    # the register-staged weight-gradient kernel (taken for tensors beyond the LDS-DMA kernel's 2 GB
-    # addressing range) gives the same gradient
+    # the other weight-gradient kernels (1: register-staged, taken for tensors beyond the 2 GB that
+    # LDS-DMA addresses; 2: per-tap LDS-DMA, taken where the all-taps kernel does not apply) give
+    # the same gradient
     from yolo_amd import _lib
-    g_dma = layer.kernel.grad.clone()
-    layer.kernel.grad = None
-    try:
-        _lib.check(_lib.lib().ymx_set_option(b"wgrad_variant", 1))
-        with T.backprop():
-            y2 = layer(xg.detach(), residual=None if scg is None else scg.detach())
-        (y2.float() * G.to(DEV)).sum().backward()
-    finally:
-        _lib.check(_lib.lib().ymx_set_option(b"wgrad_variant", 0))
-    assert _scaled_err(layer.kernel.grad.cpu(), po["kernel"].grad) < 1e-2
-    assert _scaled_err(layer.kernel.grad.cpu(), g_dma.cpu()) < 1e-5          # same products, another summation order
+    g_auto = layer.kernel.grad.clone()
+    for variant in (1, 2):
+        layer.kernel.grad = None
+        try:
+            _lib.check(_lib.lib().ymx_set_option(b"wgrad_variant", variant))
+            with T.backprop():
+                y2 = layer(xg.detach(), residual=None if scg is None else scg.detach())
+            (y2.float() * G.to(DEV)).sum().backward()
+        finally:
+            _lib.check(_lib.lib().ymx_set_option(b"wgrad_variant", 0))
+        assert _scaled_err(layer.kernel.grad.cpu(), po["kernel"].grad) < 1e-2
+        assert _scaled_err(layer.kernel.grad.cpu(), g_auto.cpu()) < 1e-5          # same products, another summation order
     # outside the context nothing is recorded and the fused inference kernels run
     y_inf = layer(xg.detach(), residual=None if scg is None else scg.detach())
     assert not y_inf.requires_grad

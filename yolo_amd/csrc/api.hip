@@ -211,7 +211,7 @@ int ymx_set_option(const char *name, long long value) {
         return YMX_OK;
     }
     if (!strcmp(name, "wgrad_variant")) {
-        if (value != 0 && value != 1) return fail(YMX_EARG, "set_option: wgrad_variant must be 0 (LDS-DMA where it applies) or 1 (register-staged)");
+        if (value < 0 || value > 2) return fail(YMX_EARG, "set_option: wgrad_variant must be 0 (automatic), 1 (register-staged) or 2 (per-tap LDS-DMA)");
         g_wgrad_variant = (int)value;
         return YMX_OK;
     }
@@ -235,6 +235,15 @@ int ymx_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Co
     if (k <= 0 || Cin <= 0 || Cout <= 0) return fail(YMX_EARG, "pack_weights: non-positive size");
     if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "pack_weights: dtype %d", dtype);
     return launch_pack_weights(w_hwio, w_packed, k, Cin, Cout, dtype, (hipStream_t)stream);
+}
+
+int ymx_pack_weights_dgrad(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dz_channels, int dtype,
+                           void *stream) {
+    if (!w_hwio || !w_packed) return fail(YMX_EARG, "pack_weights_dgrad: null pointer");
+    if (k <= 0 || Cin <= 0 || Cout <= 0) return fail(YMX_EARG, "pack_weights_dgrad: non-positive size");
+    if (dz_channels < Cout) return fail(YMX_EARG, "pack_weights_dgrad: dz_channels %d below Cout %d", dz_channels, Cout);
+    if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "pack_weights_dgrad: dtype %d", dtype);
+    return launch_pack_weights(w_hwio, w_packed, k, dz_channels, Cin, dtype, (hipStream_t)stream, Cout);
 }
 
 int ymx_conv2d_fused(const void *x, const void *w, const void *scale, const void *shift, const void *residual,

@@ -216,7 +216,7 @@ extern thread_local int g_dma2_stages;     // per calling thread, like every tun
 bool conv_first_rows_eligible(const ConvArgs &a);
 int launch_conv_direct(const ConvArgs &a, hipStream_t s);
 int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype,
-                        hipStream_t s);
+                        hipStream_t s, int src_cout = 0);
 int launch_upsample2x_concat(const void *skip, const void *x, void *y, int B, int H, int W, int C1,
                              int C2, int dtype, hipStream_t s);
 int launch_affine_act(const void *x, const float *scale, const float *shift, void *y, long long n, int C, int act,

@@ -332,16 +332,25 @@ int launch_conv_direct(const ConvArgs &a, hipStream_t s) {
 // ---- weight packing ------------------------------------------------------------
 // MFMA path: HWIO fp32 [K][Cout] -> [rows = Cout rounded up to 128][Kw = K rounded up
 // to 64] of T, row-major, zero padded; K order (r, c, ci) is HWIO's own flattening.
+// src_cout > 0 packs the kernel of the input-gradient convolution instead: w is the forward
+// kernel [taps][Cout (its input channels)][src_cout (its output channels, <= Cin)], and the
+// packed kernel is that one flipped over the taps with the two channel axes swapped (rows of
+// zeros where Cin pads src_cout).
 template <typename T>
 __global__ void __launch_bounds__(256)
 pack_weights_kernel(const float *__restrict__ w, T *__restrict__ out, int K, int Cin, int Cout, int Kw, int rows,
-                    int CB, int kb) {
+                    int CB, int kb, int src_cout, int ntaps) {
     const size_t n = (size_t)rows * Kw;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int co = (int)(i / Kw), kk = (int)(i - (size_t)co * Kw);
         // packed column kk = blk*kb + tap*CB + c  <-  HWIO row tap*Cin + blk*CB + c
         const int blk = kk / kb, rem = kk - blk * kb, tap = rem / CB, c = rem - tap * CB;
-        const float v = (co < Cout && kk < K) ? w[(size_t)(tap * Cin + blk * CB + c) * Cout + co] : 0.0f;
+        float v = 0.0f;
+        if (co < Cout && kk < K) {
+            const int ci = blk * CB + c;
+            if (src_cout == 0) v = w[(size_t)(tap * Cin + ci) * Cout + co];
+            else if (ci < src_cout) v = w[((size_t)(ntaps - 1 - tap) * Cout + co) * src_cout + ci];
+        }
         elem<T>::store(out + i, v);
     }
 }
@@ -356,9 +365,10 @@ copy_weights_kernel(const float *__restrict__ w, float *__restrict__ out, size_t
 }
 
 int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype,
-                        hipStream_t s) {
+                        hipStream_t s, int src_cout) {
     const int K = k * k * Cin;
     if (!conv_uses_mfma(Cin, dtype)) {
+        if (src_cout) return fail(YMX_EUNSUPPORTED, "pack_weights_dgrad: %d channels in dtype %d take the direct kernel", Cin, dtype);
         const size_t n = (size_t)K * Cout;
         const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
         hipLaunchKernelGGL(copy_weights_kernel, dim3(grid), dim3(256), 0, s, w_hwio, (float *)w_packed, n,
@@ -369,9 +379,9 @@ int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int
     const size_t n = (size_t)rows * Kw;
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     if (dtype == YMX_BF16)
-        hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, w_hwio, (bf16_t *)w_packed, K, Cin, Cout, Kw, rows, CB, k * k * CB);
+        hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, w_hwio, (bf16_t *)w_packed, K, Cin, Cout, Kw, rows, CB, k * k * CB, src_cout, k * k);
     else
-        hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, s, w_hwio, (float *)w_packed, K, Cin, Cout, Kw, rows, CB, k * k * CB);
+        hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, s, w_hwio, (float *)w_packed, K, Cin, Cout, Kw, rows, CB, k * k * CB, src_cout, k * k);
     return check_launch("pack_weights");
 }
 

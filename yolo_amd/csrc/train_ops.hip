@@ -633,7 +633,226 @@ conv_wgrad_dma_kernel(const WgradArgs a, const unsigned x_bytes, const unsigned 
             }
 }
 
-thread_local int g_wgrad_variant = 0;        // 0: LDS-DMA kernel where it applies; 1: register-staged kernel (tuning option "wgrad_variant")
+thread_local int g_wgrad_variant = 0;        // 0: automatic; 1: register-staged kernel; 2: per-tap LDS-DMA kernel (tuning option "wgrad_variant")
+
+// ---- weight gradient of 3x3 stride-1 layers: all nine taps from one resident slab ------------
+// The kernels above give every tap its own workgroups, so a layer's dz tiles and (shifted) x
+// tiles cross the L2 nine times: 85 FLOP per byte, and the step time is what L2 delivers.
+// For a 3x3 stride-1 convolution output pixel p and tap (r, s) meet input pixel
+// p + (r - 1) W + (s - 1) of the flattened [B*H*W] pixel axis, so one contiguous run of x rows
+// serves all nine taps of a run of output pixels (the idea of conv_igemm_halo.hip).  Here a
+// workgroup owns 64 input x 64 output channels and ALL taps (wave = 32 x 32 channels x 9
+// taps: 144 accumulator registers); per 32-pixel step it brings in 32 new x rows and 32 dz
+// rows (8 KB for 2.4 MFLOP: 295 FLOP per byte) by LDS-DMA:
+//   x rows   a ring of RX rows (a power of two, >= the 2 W + 34 rows a step touches plus the
+//            steps in flight), row of input pixel i at slot i mod RX, fetched in aligned groups
+//            of eight rows (exactly four groups per step); pixels before the tensor or after it
+//            are out-of-range offsets and arrive as zeros
+//   dz rows  a ring of NS stages of 32 rows
+//   borders  a tap that leaves the image (or wraps into the neighbouring row or image) must
+//            contribute nothing: the lane that supplies that pixel's row address to the
+//            transposing read points it at a row of zeros instead
+// Same swizzle, transposed reads, counted waits and ordered pixel slices as above.
+struct WgradSlabArgs {
+    WgradArgs w;
+    int RX;                      // rows of the x ring
+    int GW;                      // ceil((33 + W) / 8): row groups between a step's first pixel and its frontier
+    unsigned x_bytes, dz_bytes;
+};
+constexpr int WS_NS = 3;         // dz stages = steps in flight + 1
+
+// Transposing reads issued without waiting for them: the caller overlaps them with the MFMAs of
+// the fragments read before and calls lds_wait_frags (LDS operations complete in order, so
+// "at most N outstanding" says which fragments have arrived).
+__device__ __forceinline__ void lds_issue_tr4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, uint2 *r) {
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                 "ds_read_b64_tr_b16 %1, %5\n\t"
+                 "ds_read_b64_tr_b16 %2, %6\n\t"
+                 "ds_read_b64_tr_b16 %3, %7"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+                 : "memory");
+}
+template <int OUTSTANDING>
+__device__ __forceinline__ void lds_wait_frags(uint2 *r) {      // r[0..3] are valid after this
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(OUTSTANDING) : "memory");
+}
+
+__global__ void __launch_bounds__(256, 2)
+conv_wgrad_slab_kernel(const WgradSlabArgs sa) {
+    const WgradArgs &a = sa.w;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int D = WS_NS - 1;                                 // steps in flight ahead of the one computed
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wci = wave & 1, wco = wave >> 1;
+    const int tile_ci = blockIdx.x % a.n_ci_tiles, tile_co = blockIdx.x / a.n_ci_tiles;
+    const int ci0 = tile_ci * 64, co0 = tile_co * 64;
+    const int c_begin = blockIdx.z * a.chunks_per_split;        // steps of 32 pixels
+    int c_end = c_begin + a.chunks_per_split;
+    const int nsteps = (a.P + 31) / 32;
+    if (c_end > nsteps) c_end = nsteps;
+    const i32x4_t xrsrc = make_rsrc(a.x, sa.x_bytes);
+    const i32x4_t zrsrc = make_rsrc(a.dz, sa.dz_bytes);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    const int RX = sa.RX, W = a.W;
+    const unsigned dz0 = lds0 + (unsigned)(RX * 128);
+    const unsigned zrow = dz0 + (unsigned)(WS_NS * 4096);        // 128 bytes of zeros
+
+    // DMA geometry: an instruction moves eight rows of 128 bytes; lane l fills slot l & 7 of row l >> 3
+    const int d_rl = lane >> 3, d_sl = lane & 7;
+    auto issue_x_group = [&](int gi) {                           // input pixels 8 gi .. 8 gi + 7
+        const int pi = gi * 8 + d_rl;
+        const int pair = (d_sl >> 1) ^ (pi & 3);
+        const int ci = ci0 + (pair * 2 + (d_sl & 1)) * 8;
+        unsigned off = OOB;
+        if (pi >= 0 && pi < a.P && ci < a.Cin) off = (unsigned)((pi * a.x_ld + ci) * 2);
+        lds_dma16(xrsrc, lds0 + (unsigned)(((gi * 8) & (RX - 1)) * 128), off);
+    };
+    auto issue_dz = [&](int step, int stage) {                   // this wave's eight rows of the step's 32
+        const int row = wave * 8 + d_rl;
+        const int p = step * 32 + row;
+        const int pair = (d_sl >> 1) ^ (row & 3);
+        const int co = co0 + (pair * 2 + (d_sl & 1)) * 8;
+        unsigned off = OOB;
+        if (step < c_end && p < a.P && co < a.Cout) off = (unsigned)((p * a.dz_ld + co) * 2);
+        lds_dma16(zrsrc, dz0 + (unsigned)(stage * 4096 + wave * 1024), off);
+    };
+
+    f32x4_t acc[9][2][2];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[tp][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read geometry: this lane supplies the addresses of pixel rows r0 and r0 + 4 of the step
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int r0 = 8 * g + q4;
+    unsigned ablk[9][2];                                         // byte offset of (tap, channel block) inside a slab row
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        const int shift = (tp / 3 - 1) * W + (tp % 3 - 1);
+        const int key = (r0 + shift) & 3;                        // steps start at multiples of 32: the key does not move
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ablk[tp][i] = (unsigned)((((wci * 2 + i) ^ key) * 32) + p4 * 8);
+    }
+    const unsigned boff0 = (unsigned)(r0 * 128 + (((wco * 2) ^ (r0 & 3)) * 32) + p4 * 8);
+    const unsigned boff1 = (unsigned)(r0 * 128 + (((wco * 2 + 1) ^ (r0 & 3)) * 32) + p4 * 8);
+
+    // a wave whose 32 x 32 channels all lie beyond the layer's (the first layer has 8 x 32) only moves data
+    const bool live = __builtin_amdgcn_readfirstlane((ci0 + wci * 32 < a.Cin && co0 + wco * 32 < a.Cout) ? 1 : 0) != 0;
+
+    // ---- prologue: the slab up to the frontier of step c_begin + D - 1, the dz rows of those steps ----
+    if (t < 32) ((float *)(smem + RX * 128 + WS_NS * 4096))[t] = 0.0f;
+    if (c_begin < c_end) {
+        const int pb = c_begin * 32 - W - 1;
+        const int g_first = pb >= 0 ? pb / 8 : -((-pb + 7) / 8);
+        const int g_end = 4 * (c_begin + D - 1) + sa.GW;
+        for (int gi = g_first + wave; gi < g_end; gi += 4) issue_x_group(gi);
+#pragma unroll
+        for (int i = 0; i < D; ++i) issue_dz(c_begin + i, i);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int stage = 0;
+    for (int step = c_begin; step < c_end; ++step) {
+        // next transfers: the four row groups of step + D (one per wave) and its dz rows
+        issue_x_group(4 * (step + D - 1) + sa.GW + wave);
+        {
+            int ns = stage + D;
+            ns = ns >= WS_NS ? ns - WS_NS : ns;
+            issue_dz(step + D, ns);
+        }
+        if (live) {
+        // which taps of this lane's two pixels stay inside the image
+        unsigned vmask[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int p = step * 32 + r0 + 4 * h;
+            const int b = fastdiv(p, a.ohw_m, a.ohw_s), rem = p - b * (a.H * W);
+            const int oh = fastdiv(rem, a.ow_m, a.ow_s), ow = rem - oh * W;
+            const unsigned ym = (oh > 0 ? 1u : 0u) | 2u | (oh < a.H - 1 ? 4u : 0u);
+            const unsigned xm = (ow > 0 ? 1u : 0u) | 2u | (ow < W - 1 ? 4u : 0u);
+            vmask[h] = ((ym & 1u) ? xm : 0u) | ((ym & 2u) ? (xm << 3) : 0u) | ((ym & 4u) ? (xm << 6) : 0u);
+        }
+        const unsigned zb = dz0 + (unsigned)(stage * 4096);
+        const int pbase = step * 32 + r0;
+        auto issue_tap = [&](int tp, uint2 *r) {
+            const int shift = (tp / 3 - 1) * W + (tp % 3 - 1);
+            const unsigned ra = ((vmask[0] >> tp) & 1u) ? lds0 + (unsigned)(((pbase + shift) & (RX - 1)) * 128) : zrow;
+            const unsigned rb = ((vmask[1] >> tp) & 1u) ? lds0 + (unsigned)(((pbase + 4 + shift) & (RX - 1)) * 128) : zrow;
+            lds_issue_tr4(ra + ablk[tp][0], rb + ablk[tp][0], ra + ablk[tp][1], rb + ablk[tp][1], r);
+        };
+        uint2 rb4[4], ra4[2][4];
+        lds_issue_tr4(zb + boff0, zb + boff0 + 512, zb + boff1, zb + boff1 + 512, rb4);
+        issue_tap(0, ra4[0]);
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            // the next tap's reads travel while this tap's products are formed
+            if (tp < 8) {
+                issue_tap(tp + 1, ra4[(tp + 1) & 1]);
+                if (tp == 0) lds_wait_frags<4>(rb4);
+                lds_wait_frags<4>(ra4[tp & 1]);
+            } else {
+                lds_wait_frags<0>(ra4[tp & 1]);
+            }
+            const uint2 *r = ra4[tp & 1];
+            const uint4 fa[2] = {make_uint4(r[0].x, r[0].y, r[1].x, r[1].y), make_uint4(r[2].x, r[2].y, r[3].x, r[3].y)};
+            const uint4 fb[2] = {make_uint4(rb4[0].x, rb4[0].y, rb4[1].x, rb4[1].y), make_uint4(rb4[2].x, rb4[2].y, rb4[3].x, rb4[3].y)};
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[i]),
+                                                                             __builtin_bit_cast(bf16x8_t, fb[j]), acc[tp][i][j], 0, 0, 0);
+        }
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * 2) : "memory");   // the next step's rows (this wave's part) have landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage = stage + 1 == WS_NS ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        float *out = a.out + ((size_t)blockIdx.z * 9 + tp) * a.Cin * a.Cout;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = ci0 + wci * 32 + i * 16 + 4 * (lane >> 4) + r;
+                    const int co = co0 + wco * 32 + j * 16 + (lane & 15);
+                    if (ci < a.Cin && co < a.Cout) out[(size_t)ci * a.Cout + co] = acc[tp][i][j][r];
+                }
+    }
+}
+
+static int wgrad_slab_rx(int W) {
+    const int need = 32 * (WS_NS - 1) + 2 * W + 41;
+    int rx = 128;
+    while (rx < need) rx <<= 1;
+    return rx;
+}
+static bool wgrad_use_slab(int k, int stride, int W, long long x_bytes, long long dz_bytes) {
+    return g_wgrad_variant == 0 && k == 3 && stride == 1 && x_bytes < 0x7fffffffLL && dz_bytes < 0x7fffffffLL && wgrad_slab_rx(W) <= 1024;
+}
+static int wgrad_slab_splits(int Cin, int Cout, long long P, int W) {
+    const long long base = (long long)((Cin + 63) / 64) * ((Cout + 63) / 64);
+    // one full round of workgroups: two fit a CU by registers, one where the ring takes most of the LDS
+    const long long slots = wgrad_slab_rx(W) > 512 ? 256 : 512;
+    long long splits = (slots + base - 1) / base;
+    const long long nsteps = (P + 31) / 32;
+    if (splits > nsteps / 8) splits = nsteps / 8;                // at least 256 pixels per slice
+    if (splits > 256) splits = 256;
+    return (int)(splits < 1 ? 1 : splits);
+}
+
 
 static int wgrad_tci(int Cin, bool dma) { return dma ? (Cin > 128 ? 256 : (Cin > 64 ? 128 : 64)) : (Cin > 64 ? 128 : 64); }
 static bool wgrad_use_dma(long long x_bytes, long long dz_bytes) {
@@ -652,7 +871,11 @@ static long long wgrad_bytes(long long pixels, int ld) { return pixels * ld * 2;
 size_t conv_wgrad_workspace_bytes(int k, int Cin, int Cout, long long P) {
     // the larger of the two kernels' needs (which one runs depends on the tensors' sizes and the option)
     const int s0 = wgrad_splits(k, Cin, Cout, P, false), s1 = wgrad_splits(k, Cin, Cout, P, true);
-    const int splits = s0 > s1 ? s0 : s1;
+    int splits = s0 > s1 ? s0 : s1;
+    if (k == 3) {
+        const int s2 = wgrad_slab_splits(Cin, Cout, P, 1);          // the narrow-ring case has the most slices
+        splits = s2 > splits ? s2 : splits;
+    }
     return splits > 1 ? (size_t)splits * k * k * Cin * Cout * 4 : 0;
 }
 
@@ -672,6 +895,27 @@ int launch_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float 
     set_fastdiv((unsigned)a.OW, a.ow_m, a.ow_s);
     set_fastdiv((unsigned)(a.OH * a.OW), a.ohw_m, a.ohw_s);
     const long long xb = wgrad_bytes((long long)B * H * W, a.x_ld), zb = wgrad_bytes(P, a.dz_ld);
+    if (wgrad_use_slab(k, stride, W, xb, zb)) {
+        WgradSlabArgs sa;
+        const int splits = wgrad_slab_splits(Cin, Cout, P, W);
+        const int nsteps = (int)((P + 31) / 32);
+        a.chunks_per_split = (nsteps + splits - 1) / splits;
+        a.n_ci_tiles = (Cin + 63) / 64;
+        a.out = splits > 1 ? (float *)ws : dw;
+        sa.w = a;
+        sa.RX = wgrad_slab_rx(W);
+        sa.GW = (33 + W + 7) / 8;
+        sa.x_bytes = (unsigned)xb; sa.dz_bytes = (unsigned)zb;
+        const int lds = sa.RX * 128 + WS_NS * 4096 + 128;
+        static LdsReserve reserved;
+        if (const int rc = reserve_lds(reserved, (const void *)conv_wgrad_slab_kernel, 144 * 1024, "conv_wgrad_slab")) return rc;
+        hipLaunchKernelGGL(conv_wgrad_slab_kernel, dim3(a.n_ci_tiles * ((Cout + 63) / 64), 1, splits), dim3(256), lds, s, sa);
+        int rc = check_launch("conv_wgrad_slab");
+        if (rc || splits == 1) return rc;
+        const size_t n = (size_t)9 * Cin * Cout;
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0, s, (const float *)ws, dw, n, splits);
+        return check_launch("conv_wgrad_reduce");
+    }
     const bool dma = wgrad_use_dma(xb, zb);
     const int splits = wgrad_splits(k, Cin, Cout, P, dma);
     const int tci = wgrad_tci(Cin, dma);

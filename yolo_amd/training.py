@@ -66,15 +66,6 @@ def _pad_channels(t, mult=8):
     return out
 
 
-def _pack(kernel_hwio, dtype):
-    k, _, cin, cout = kernel_hwio.shape
-    code = _lib.dtype_code(dtype)
-    src = kernel_hwio.detach().float().contiguous()
-    wp = torch.empty(_lib.lib().ymx_packed_weight_bytes(k, cin, cout, code), dtype=torch.uint8, device=src.device)
-    _lib.launch("ymx_pack_weights", wp, _lib.ptr(src), _lib.ptr(wp), k, cin, cout, code)
-    return wp, src
-
-
 def _conv(x, wp, shift, cin, cout, k, stride, cdt, odt):
     b, h, w, _ = x.shape
     oh, ow = (h, w) if stride == 1 else ((h + 1 - k) // 2 + 1, (w + 1 - k) // 2 + 1)
@@ -163,10 +154,9 @@ class _ConvBlock(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             # d loss / d x = conv(dz, kernel flipped over the taps, input and output channels swapped)
-            wd = kernel.detach().flip(0, 1).permute(0, 1, 3, 2)
-            if coutp != cout:
-                wd = torch.cat([wd, torch.zeros((k, k, coutp - cout, cin), device=wd.device, dtype=wd.dtype)], dim=2)
-            wdp, _keep = _pack(wd, cdt)
+            src_k = kernel.detach().float().contiguous()
+            wdp = torch.empty(L.ymx_packed_weight_bytes(k, coutp, cin, code), dtype=torch.uint8, device=x.device)
+            _lib.launch("ymx_pack_weights_dgrad", wdp, _lib.ptr(src_k), _lib.ptr(wdp), k, cin, cout, coutp, code)
             src = dzp
             if stride == 2:
                 if k != 3:
