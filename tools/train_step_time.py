@@ -1,6 +1,7 @@
 """Times one training step of the detector on one GPU (tuning aid):
 forward with the graph recorded, the YOLO loss at the three scales, backward through every
-block, plain SGD.      python tools/train_step_time.py [batch] [size] [steps]"""
+block, plain SGD.      python tools/train_step_time.py [batch] [size] [steps]
+env: LR, WGRAD (option wgrad_variant), OVERLAP (0: weight gradients on the main stream)"""
 import os
 import sys
 import time
@@ -49,6 +50,8 @@ def main():
     fns = L.get_yolo_loss_at_scales([0, 1, 2], C, cfg["strides"], 0.5, cfg["xyscale"], cfg["anchors"])   # order: scales 2, 1, 0
     targets = make_targets(B, size, C, np.random.default_rng(0))
     lr = float(os.environ.get("LR", "1e-7"))
+    if os.environ.get("OVERLAP"):
+        T.overlap_wgrad = bool(int(os.environ["OVERLAP"]))
 
     def step():
         with T.backprop():

@@ -659,7 +659,7 @@ struct WgradSlabArgs {
     int GW;                      // ceil((33 + W) / 8): row groups between a step's first pixel and its frontier
     unsigned x_bytes, dz_bytes;
 };
-constexpr int WS_NS = 3;         // dz stages = steps in flight + 1
+constexpr int WS_NS = 3;         // dz stages = steps in flight + 1 (a fourth stage gains 2 % at 52 x 52 and costs the second workgroup per CU at 104 x 104)
 
 // Transposing reads issued without waiting for them: the caller overlaps them with the MFMAs of
 // the fragments read before and calls lds_wait_frags (LDS operations complete in order, so
@@ -731,13 +731,13 @@ conv_wgrad_slab_kernel(const WgradSlabArgs sa) {
     // transposed-read geometry: this lane supplies the addresses of pixel rows r0 and r0 + 4 of the step
     const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int r0 = 8 * g + q4;
-    unsigned ablk[9][2];                                         // byte offset of (tap, channel block) inside a slab row
+    unsigned ablk[9][2];                                         // LDS address of (tap, channel block) inside slab row 0
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
         const int shift = (tp / 3 - 1) * W + (tp % 3 - 1);
         const int key = (r0 + shift) & 3;                        // steps start at multiples of 32: the key does not move
 #pragma unroll
-        for (int i = 0; i < 2; ++i) ablk[tp][i] = (unsigned)((((wci * 2 + i) ^ key) * 32) + p4 * 8);
+        for (int i = 0; i < 2; ++i) ablk[tp][i] = lds0 + (unsigned)((((wci * 2 + i) ^ key) * 32) + p4 * 8);
     }
     const unsigned boff0 = (unsigned)(r0 * 128 + (((wco * 2) ^ (r0 & 3)) * 32) + p4 * 8);
     const unsigned boff1 = (unsigned)(r0 * 128 + (((wco * 2 + 1) ^ (r0 & 3)) * 32) + p4 * 8);
@@ -769,38 +769,48 @@ conv_wgrad_slab_kernel(const WgradSlabArgs sa) {
         }
         if (live) {
         // which taps of this lane's two pixels stay inside the image
-        unsigned vmask[2];
+        // (kept as lane masks: the per-tap tests are then scalar ANDs and one select per address)
+        bool up[2], down[2], left[2], right[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int p = step * 32 + r0 + 4 * h;
             const int b = fastdiv(p, a.ohw_m, a.ohw_s), rem = p - b * (a.H * W);
             const int oh = fastdiv(rem, a.ow_m, a.ow_s), ow = rem - oh * W;
-            const unsigned ym = (oh > 0 ? 1u : 0u) | 2u | (oh < a.H - 1 ? 4u : 0u);
-            const unsigned xm = (ow > 0 ? 1u : 0u) | 2u | (ow < W - 1 ? 4u : 0u);
-            vmask[h] = ((ym & 1u) ? xm : 0u) | ((ym & 2u) ? (xm << 3) : 0u) | ((ym & 4u) ? (xm << 6) : 0u);
+            up[h] = oh > 0; down[h] = oh < a.H - 1; left[h] = ow > 0; right[h] = ow < W - 1;
         }
         const unsigned zb = dz0 + (unsigned)(stage * 4096);
-        const int pbase = step * 32 + r0;
+        // ring positions in bytes: (row & (RX - 1)) * 128 == (row * 128) & ((RX - 1) * 128)
+        const unsigned ring_mask = (unsigned)((RX - 1) * 128);
+        const unsigned pb0 = (unsigned)((step * 32 + r0) * 128), pb1 = pb0 + 512u;
         auto issue_tap = [&](int tp, uint2 *r) {
-            const int shift = (tp / 3 - 1) * W + (tp % 3 - 1);
-            const unsigned ra = ((vmask[0] >> tp) & 1u) ? lds0 + (unsigned)(((pbase + shift) & (RX - 1)) * 128) : zrow;
-            const unsigned rb = ((vmask[1] >> tp) & 1u) ? lds0 + (unsigned)(((pbase + 4 + shift) & (RX - 1)) * 128) : zrow;
+            const int tr = tp / 3, tc = tp % 3;
+            const unsigned shift_b = (unsigned)(((tr - 1) * W + (tc - 1)) * 128);       // wave-uniform
+            bool ok0 = true, ok1 = true;
+            if (tr == 0) { ok0 = ok0 && up[0]; ok1 = ok1 && up[1]; }
+            if (tr == 2) { ok0 = ok0 && down[0]; ok1 = ok1 && down[1]; }
+            if (tc == 0) { ok0 = ok0 && left[0]; ok1 = ok1 && left[1]; }
+            if (tc == 2) { ok0 = ok0 && right[0]; ok1 = ok1 && right[1]; }
+            const unsigned ra = ok0 ? ((pb0 + shift_b) & ring_mask) : zrow - lds0;     // ablk carries lds0
+            const unsigned rb = ok1 ? ((pb1 + shift_b) & ring_mask) : zrow - lds0;
             lds_issue_tr4(ra + ablk[tp][0], rb + ablk[tp][0], ra + ablk[tp][1], rb + ablk[tp][1], r);
         };
-        uint2 rb4[4], ra4[2][4];
+        uint2 rb4[4], ra4[3][4];
         lds_issue_tr4(zb + boff0, zb + boff0 + 512, zb + boff1, zb + boff1 + 512, rb4);
         issue_tap(0, ra4[0]);
+        issue_tap(1, ra4[1]);
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
-            // the next tap's reads travel while this tap's products are formed
-            if (tp < 8) {
-                issue_tap(tp + 1, ra4[(tp + 1) & 1]);
-                if (tp == 0) lds_wait_frags<4>(rb4);
-                lds_wait_frags<4>(ra4[tp & 1]);
+            // the reads of the next two taps travel while this tap's products are formed
+            if (tp < 7) {
+                issue_tap(tp + 2, ra4[(tp + 2) % 3]);
+                if (tp == 0) lds_wait_frags<8>(rb4);
+                lds_wait_frags<8>(ra4[tp % 3]);
+            } else if (tp == 7) {
+                lds_wait_frags<4>(ra4[tp % 3]);
             } else {
-                lds_wait_frags<0>(ra4[tp & 1]);
+                lds_wait_frags<0>(ra4[tp % 3]);
             }
-            const uint2 *r = ra4[tp & 1];
+            const uint2 *r = ra4[tp % 3];
             const uint4 fa[2] = {make_uint4(r[0].x, r[0].y, r[1].x, r[1].y), make_uint4(r[2].x, r[2].y, r[3].x, r[3].y)};
             const uint4 fb[2] = {make_uint4(rb4[0].x, rb4[0].y, rb4[1].x, rb4[1].y), make_uint4(rb4[2].x, rb4[2].y, rb4[3].x, rb4[3].y)};
 #pragma unroll

@@ -51,6 +51,18 @@ class backprop(object):
         return False
 
 
+overlap_wgrad = True        # weight gradients on a second HIP stream, next to the input gradients
+_side = {}
+
+
+def _side_stream(device):
+    key = (threading.get_ident(), device.index if device.index is not None else torch.cuda.current_device())
+    st = _side.get(key)
+    if st is None:
+        st = _side[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _empty(shape, like, dtype=None):
     return torch.empty(shape, device=like.device, dtype=dtype or like.dtype)
 
@@ -140,17 +152,27 @@ class _ConvBlock(torch.autograd.Function):
             _lib.launch("ymx_bias_grad", dzp, _lib.ptr(dzp), npix, coutp, 0, code, _lib.ptr(dbp), _lib.ptr(ws), nb)
             dbias = dbp[:cout]
         dkernel = None
+        side = None
         if ctx.needs_input_grad[1]:
             xp = _pad_channels(x.to(cdt))
             cinp = xp.shape[-1]
             dwp = torch.empty((k, k, cinp, coutp), device=x.device, dtype=torch.float32)
             nb = L.ymx_conv_wgrad_workspace_bytes(b, h, w, cinp, coutp, k, stride)
             ws = torch.empty((max(nb, 16),), device=x.device, dtype=torch.uint8)
-            _lib.launch("ymx_conv_wgrad", xp, _lib.ptr(xp), 0, _lib.ptr(dzp), 0, _lib.ptr(dwp), b, h, w, cinp, coutp, k, stride,
-                        _lib.ptr(ws), nb)
-            dkernel = dwp[:, :, :cin, :cout]
-            if dkernel.shape != dwp.shape:
-                dkernel = dkernel.contiguous()
+            # the weight gradient and the input gradient of a block are independent: the former
+            # runs on a second stream while this one goes on with the latter
+            side = _side_stream(x.device) if (overlap_wgrad and ctx.needs_input_grad[0]) else None
+            if side is not None:
+                main = torch.cuda.current_stream(x.device)
+                side.wait_stream(main)
+                for t_ in (xp, dzp, dwp, ws):
+                    t_.record_stream(side)
+                with torch.cuda.stream(side):
+                    _lib.launch("ymx_conv_wgrad", xp, _lib.ptr(xp), 0, _lib.ptr(dzp), 0, _lib.ptr(dwp), b, h, w, cinp, coutp, k, stride,
+                                _lib.ptr(ws), nb)
+            else:
+                _lib.launch("ymx_conv_wgrad", xp, _lib.ptr(xp), 0, _lib.ptr(dzp), 0, _lib.ptr(dwp), b, h, w, cinp, coutp, k, stride,
+                            _lib.ptr(ws), nb)
         dx = None
         if ctx.needs_input_grad[0]:
             # d loss / d x = conv(dz, kernel flipped over the taps, input and output channels swapped)
@@ -166,6 +188,12 @@ class _ConvBlock(torch.autograd.Function):
             dx = _conv(src, wdp, None, coutp, cin, k, 1, cdt, cdt)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
+        if ctx.needs_input_grad[1]:
+            if side is not None:
+                torch.cuda.current_stream(x.device).wait_stream(side)
+            dkernel = dwp[:, :, :cin, :cout]
+            if dkernel.shape != dwp.shape:
+                dkernel = dkernel.contiguous()
         dshortcut = None
         if ctx.has_shortcut and ctx.needs_input_grad[3]:
             dshortcut = dy.to(ctx.shortcut_dtype)
