@@ -92,6 +92,63 @@ def test_conv_block_gradients(case):
     assert not y_inf.requires_grad
 
 
+FULL_LAYERS = [   # B, H, Cin, Cout, k, stride: the detector's own layer shapes at 416 x 416
+    (1, 52, 512, 1024, 3, 1),      # the head's widest layer: 169 32-pixel steps, 4 pixel slices
+    (2, 26, 512, 1024, 3, 1),
+    (3, 13, 512, 1024, 3, 1),      # image borders every 13 pixels, three images in one ring
+    (1, 104, 64, 128, 3, 1),       # 512-row ring
+    (1, 208, 32, 64, 3, 1),        # 1024-row ring
+    (1, 416, 8, 32, 3, 1),         # first layer (channels padded 3 -> 8): one live wave per workgroup
+    (1, 416, 32, 64, 3, 2),        # stride 2: per-tap kernels
+    (1, 52, 256, 512, 3, 2),
+    (2, 52, 256, 128, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", range(len(FULL_LAYERS)))
+def test_weight_gradient_at_full_layer_sizes(case):
+    """ymx_conv_wgrad through the C ABI on whole layers of the detector, all three kernels,
+    against the fp32 CPU derivative of the oracle's convolution (same bf16 inputs: the
+    products are exact in fp32, only the order of the sum differs)."""
+    from yolo_amd import _lib
+    B, H, cin, cout, k, stride = FULL_LAYERS[case]
+    g = torch.Generator().manual_seed(900 + case)
+    oh = H if stride == 1 else (H + 1 - k) // 2 + 1
+    x = N.bf16_round(torch.randn(B, H, H, cin, generator=g))
+    dz = N.bf16_round(torch.randn(B, oh, oh, cout, generator=g))
+    if cin == 8:
+        x[..., 3:] = 0                                   # the padding channels of the first layer
+    xc, dzc = x.permute(0, 3, 1, 2).contiguous(), dz.permute(0, 3, 1, 2).contiguous()
+    if stride == 2:                                      # one zero row / column on the top and left, then VALID (layers.py:46-54)
+        xc = torch.nn.functional.pad(xc, (1, 0, 1, 0))
+        want = torch.nn.grad.conv2d_weight(xc, (cout, cin, k, k), dzc, stride=2, padding=0)
+    else:
+        want = torch.nn.grad.conv2d_weight(xc, (cout, cin, k, k), dzc, stride=1, padding=(k - 1) // 2)
+    want = want.permute(2, 3, 1, 0).contiguous()         # OIHW -> HWIO
+    L = _lib.lib()
+    xg, dzg = x.to(DEV).bfloat16(), dz.to(DEV).bfloat16()
+    got = {}
+    for variant in (0, 1, 2):
+        dw = torch.full((k, k, cin, cout), float("nan"), device=DEV)
+        try:
+            _lib.check(L.ymx_set_option(b"wgrad_variant", variant))
+            nb = L.ymx_conv_wgrad_workspace_bytes(B, H, H, cin, cout, k, stride)
+            ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+            _lib.launch("ymx_conv_wgrad", xg, _lib.ptr(xg), 0, _lib.ptr(dzg), 0, _lib.ptr(dw), B, H, H, cin, cout, k, stride, _lib.ptr(ws), nb)
+        finally:
+            _lib.check(L.ymx_set_option(b"wgrad_variant", 0))
+        got[variant] = dw.cpu()
+        e = _scaled_err(got[variant], want)
+        print("wgrad variant %d, %s: scaled error %.2e" % (variant, FULL_LAYERS[case], e))
+        assert e < 1e-4, (variant, e)
+    # launching again gives the same bits (ordered partial sums, no float atomics)
+    dw2 = torch.empty((k, k, cin, cout), device=DEV)
+    nb = L.ymx_conv_wgrad_workspace_bytes(B, H, H, cin, cout, k, stride)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    _lib.launch("ymx_conv_wgrad", xg, _lib.ptr(xg), 0, _lib.ptr(dzg), 0, _lib.ptr(dw2), B, H, H, cin, cout, k, stride, _lib.ptr(ws), nb)
+    assert torch.equal(dw2.cpu(), got[0])
+
+
 def test_upsample_concat_gradient():
     from yolo_amd import training as T
     from yolo_amd.layers import upsample2x_concat
