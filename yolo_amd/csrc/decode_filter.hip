@@ -212,6 +212,7 @@ decode_kernel(const DecodeArgs a) {
 #pragma unroll
     for (int k = 0; k < CPT; ++k) p_score[k] = 0.f;
     u64 *st = a.state + (size_t)b * a.nseg;
+    const int l2_polls = (gridDim.x % 8 == 0) ? 16 : 0;     // see the look-back below
 
     int dstamp_it = 0;       // iteration counter (only the diagnostic build reads it)
     (void)dstamp_it;
@@ -342,7 +343,17 @@ decode_kernel(const DecodeArgs a) {
                     u64 v = YMX_ST_PREFIX;                      // before the first segment: prefix 0
                     int spin = 0;
                     for (;;) {
-                        if (p >= 0) v = __hip_atomic_load(&st[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // The first polls read through the L2 of this XCD only (workgroup scope skips just the
+                        // per-CU cache): the workgroups of an image are dispatched to one XCD when the batch
+                        // is a multiple of 8 (workgroup id mod 8 = image mod 8; other batches poll
+                        // device-coherently from the start), where the publishing stores
+                        // have updated that L2 on their way to memory -- a fraction of the round trip of a
+                        // device-coherent load.  A word can only look older than it is (not yet published, or
+                        // an aggregate where a prefix exists), both of which are safe to act on; whatever is
+                        // still missing after sixteen short polls is read device-coherently as before.
+                        if (p >= 0)
+                            v = spin < l2_polls ? __hip_atomic_load(&st[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                         : __hip_atomic_load(&st[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const u64 ready = __ballot((v >> 62) != 0);
                         const u64 prefix = __ballot((v >> 62) == 2);
                         const u64 pfirst = prefix & (~prefix + 1);            // lowest set bit, 0 if none
@@ -357,7 +368,8 @@ decode_kernel(const DecodeArgs a) {
                             break;
                         }
                         if (++spin > (1 << 20)) { failed = true; break; }
-                        __builtin_amdgcn_s_sleep(16);
+                        if (spin <= l2_polls) __builtin_amdgcn_s_sleep(4);
+                        else __builtin_amdgcn_s_sleep(16);
                     }
                 }
                 if (lane == 0) {
