@@ -29,6 +29,9 @@ CASES = [   # B, H, W, Cin, Cout, k, downsample, act, shortcut
     (1, 13, 13, 256, 512, 3, False, "leaky", False),      # a slice shorter than the ring's run-in
     (1, 208, 208, 8, 16, 3, False, "leaky", False),       # 1024-row ring (one workgroup per CU)
     (1, 500, 500, 8, 16, 3, False, "leaky", False),       # too wide for the ring: per-tap kernel
+    (1, 52, 52, 64, 128, 3, True, "leaky", False),        # stride 2 at a layer's real width
+    (2, 26, 30, 40, 72, 3, True, "mish", False),          # the same with channel counts off the tile sizes
+    (2, 12, 8, 16, 255, 3, True, None, False),            # and an output channel count that is padded (255 -> 256)
 ]
 
 
