@@ -130,31 +130,41 @@ sum_partials_kernel(const float *__restrict__ partial, float *__restrict__ out, 
 }
 
 // The same for short vectors (bias gradients: n = channels) where a thread per element would
-// leave the GPU to a handful of serial loops: 32 elements x 8 part lanes per workgroup, lane l
-// adds parts l, l + 8, ... and the eight lane sums are added in order.
-__global__ void __launch_bounds__(256)
+// leave the GPU to a handful of serial loops: 32 elements x 32 part lanes per workgroup, lane l
+// adds parts l, l + 32, ... and the 32 lane sums are added in order.
+__global__ void __launch_bounds__(1024)
 sum_partials_small_kernel(const float *__restrict__ partial, float *__restrict__ out, int n, int parts) {
-    __shared__ float red[8][32];
+    __shared__ float red[32][32];
     const int t = threadIdx.x, e = t & 31, pl = t >> 5;
     const int i = blockIdx.x * 32 + e;
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
     if (i < n) {
         int s = pl;
-        for (; s + 24 < parts; s += 32) {
-            const float v0 = partial[(size_t)s * n + i], v1 = partial[(size_t)(s + 8) * n + i];
-            const float v2 = partial[(size_t)(s + 16) * n + i], v3 = partial[(size_t)(s + 24) * n + i];
+        for (; s + 96 < parts; s += 128) {
+            const float v0 = partial[(size_t)s * n + i], v1 = partial[(size_t)(s + 32) * n + i];
+            const float v2 = partial[(size_t)(s + 64) * n + i], v3 = partial[(size_t)(s + 96) * n + i];
             a0 += v0; a1 += v1; a2 += v2; a3 += v3;
         }
-        for (; s < parts; s += 8) a0 += partial[(size_t)s * n + i];
+        for (; s < parts; s += 32) a0 += partial[(size_t)s * n + i];
     }
     red[pl][e] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (t < 32 && i < n) {
         float sum = 0.0f;
 #pragma unroll
-        for (int l = 0; l < 8; ++l) sum += red[l][t];
+        for (int l = 0; l < 32; ++l) sum += red[l][t];
         out[i] = sum;
     }
+}
+
+// Partial weight gradients: short tensors with many slices (1x1 layers: 8 K - 256 K elements,
+// up to 256 slices) go through the part-lane form too, where a thread per element would walk
+// the slices one load round trip after the other.
+static void launch_sum_partials(const float *partial, float *out, size_t n, int parts, hipStream_t s) {
+    if (n <= (1u << 18) && parts >= 8)
+        hipLaunchKernelGGL(sum_partials_small_kernel, dim3((unsigned)((n + 31) / 32)), dim3(1024), 0, s, partial, out, (int)n, parts);
+    else
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0, s, partial, out, n, parts);
 }
 
 // bf16 rows whose 16-byte chunks divide the workgroup (C / 8 a power of two up to 256, dense
@@ -206,7 +216,7 @@ int launch_bias_grad(const void *dz, long long P, int C, int ld, int dtype, floa
     else hipLaunchKernelGGL(colsum_kernel<float>, dim3(parts), dim3(256), 0, s, (const float *)dz, partial, P, C, ld, rows_per);
     int rc = check_launch("bias_grad");
     if (rc) return rc;
-    hipLaunchKernelGGL(sum_partials_small_kernel, dim3((C + 31) / 32), dim3(256), 0, s, partial, db, C, parts);
+    hipLaunchKernelGGL(sum_partials_small_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, partial, db, C, parts);
     return check_launch("bias_grad_reduce");
 }
 
@@ -266,7 +276,7 @@ int launch_act_bwd_bias(const void *z, const void *dy, void *dz, long long P, in
     hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(parts), dim3(256), 0, s, (const uint4 *)z, (const uint4 *)dy, (uint4 *)dz, (float *)ws, n8, C, act);
     int rc = check_launch("act_backward_bias");
     if (rc) return rc;
-    hipLaunchKernelGGL(sum_partials_small_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const float *)ws, db, C, parts);
+    hipLaunchKernelGGL(sum_partials_small_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, (const float *)ws, db, C, parts);
     return check_launch("act_backward_bias_reduce");
 }
 
@@ -923,7 +933,7 @@ int launch_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float 
         int rc = check_launch("conv_wgrad_slab");
         if (rc || splits == 1) return rc;
         const size_t n = (size_t)9 * Cin * Cout;
-        hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0, s, (const float *)ws, dw, n, splits);
+        launch_sum_partials((const float *)ws, dw, n, splits, s);
         return check_launch("conv_wgrad_reduce");
     }
     const bool dma = wgrad_use_dma(xb, zb);
@@ -955,7 +965,7 @@ int launch_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float 
     int rc = check_launch("conv_wgrad");
     if (rc || splits == 1) return rc;
     const size_t n = (size_t)k * k * Cin * Cout;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0, s, (const float *)ws, dw, n, splits);
+    launch_sum_partials((const float *)ws, dw, n, splits, s);
     return check_launch("conv_wgrad_reduce");
 }
 
