@@ -224,7 +224,7 @@ def test_small_network_gradients_and_descent():
             layer.kernel.grad = None
             layer.bias.grad = None
         loss.backward()
-        return float(loss)
+        return float(loss.detach())
 
     got_loss = step()
     assert abs(got_loss - want_loss) < 2e-2 * abs(want_loss)
