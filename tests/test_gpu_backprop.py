@@ -152,6 +152,50 @@ def test_weight_gradient_at_full_layer_sizes(case):
     assert torch.equal(dw2.cpu(), got[0])
 
 
+def test_residial_block_gradients():
+    """x + conv3x3(conv1x1(x)) (layers.py:92-106): the gradient of x is the sum of the path through
+    the two convolutions and of the shortcut; on the GPU the second term is added inside the
+    first block's input-gradient convolution instead of by autograd."""
+    from yolo_amd import training as T
+    from yolo_amd.layers import ResidialBlock
+    B, H, W, c1, c2 = 2, 12, 10, 32, 64
+    g = torch.Generator().manual_seed(77)
+    x = N.bf16_round(torch.randn(B, H, W, c2, generator=g))
+    p1 = {"kernel": N.bf16_round(torch.randn(1, 1, c2, c1, generator=g) * (2.0 / c2) ** 0.5), "bias": N.bf16_round(0.1 * torch.randn(c1, generator=g))}
+    p2 = {"kernel": N.bf16_round(torch.randn(3, 3, c1, c2, generator=g) * (2.0 / (9 * c1)) ** 0.5), "bias": N.bf16_round(0.1 * torch.randn(c2, generator=g))}
+    G = N.bf16_round(torch.randn(B, H, W, c2, generator=g))
+    # a layer in front, so that x is not a leaf (the usual place of a block in the network) and
+    # the shortcut's gradient has to pass through two blocks' backward functions
+    xo = x.clone().requires_grad_(True)
+    po = [{n: v.clone().requires_grad_(True) for n, v in p.items()} for p in (p1, p2)]
+    yo = xo * 1.0
+    yo = yo + N.yolo_conv(N.yolo_conv(yo, po[0], False, "mish"), po[1], False, "mish")
+    (yo * G).sum().backward()
+    blk = ResidialBlock(c1, c2, activation="mish", dtype=torch.bfloat16)
+    blk.layer_stack[0].load_reference_params(p1)
+    blk.layer_stack[1].load_reference_params(p2)
+    blk.to(DEV)
+    xg = x.to(DEV).bfloat16().requires_grad_(True)
+    with T.backprop():
+        yg = blk(xg * 1.0)
+    assert _scaled_err(yg.detach().float().cpu(), yo.detach()) < 1e-2
+    (yg.float() * G.to(DEV)).sum().backward()
+    errs = {"x": _scaled_err(xg.grad.float().cpu(), xo.grad)}
+    for i, layer in enumerate(blk.layer_stack):
+        errs["kernel%d" % i] = _scaled_err(layer.kernel.grad.cpu(), po[i]["kernel"].grad)
+        errs["bias%d" % i] = _scaled_err(layer.bias.grad.cpu(), po[i]["bias"].grad)
+    print("ResidialBlock gradient errors:", errs)
+    for name, e in errs.items():
+        assert e < 1e-2, (name, e)
+    # a block whose input needs no gradient (the shortcut is a constant) still trains its kernels
+    for layer in blk.layer_stack:
+        layer.kernel.grad = None
+    with T.backprop():
+        y2 = blk(x.to(DEV).bfloat16())
+    (y2.float() * G.to(DEV)).sum().backward()
+    assert _scaled_err(blk.layer_stack[0].kernel.grad.cpu(), po[0]["kernel"].grad) < 1e-2
+
+
 def test_upsample_concat_gradient():
     from yolo_amd import training as T
     from yolo_amd.layers import upsample2x_concat

@@ -241,7 +241,7 @@ class YOLOConv(nn.Module):
         return (h + 1 - k) // 2 + 1, (w + 1 - k) // 2 + 1
 
     # -- forward ----------------------------------------------------------------
-    def forward(self, x, residual=None, out_dtype=None, out=None):
+    def forward(self, x, residual=None, out_dtype=None, out=None, _grad_link=None):
         """x NHWC -> NHWC.  residual (same shape as the output) is added after the
         activation inside the kernel; out_dtype overrides the output element type; out, if
         given, receives the result: a [B,H',W',Cout] view whose pixels may be spaced wider than
@@ -256,7 +256,7 @@ class YOLOConv(nn.Module):
             # differentiable path (yolo_amd.training): z = conv(x) kept, y = act(z) + shortcut
             if out is not None:
                 raise ValueError("YOLOConv: out= is not supported while back-propagation is recorded")
-            y = _training.conv_block(self, x, residual)
+            y = _training.conv_block(self, x, residual, _grad_link)
             return y if out_dtype in (None, y.dtype) else y.to(out_dtype)
         cdt = self.compute_dtype or x.dtype
         code = _lib.dtype_code(cdt)
@@ -314,5 +314,10 @@ class ResidialBlock(nn.Module):
 
     def forward(self, x, out=None):
         short_cut = x
+        if _training.enabled() and torch.is_tensor(x) and x.requires_grad and x.dtype == torch.bfloat16:
+            # both blocks see x: the second hands the shortcut's gradient to the first (training.GradLink)
+            link = _training.GradLink()
+            x = self.layer_stack[0](x, _grad_link=link)
+            return self.layer_stack[1](x, residual=short_cut, out=out, _grad_link=link)
         x = self.layer_stack[0](x)
         return self.layer_stack[1](x, residual=short_cut, out=out)

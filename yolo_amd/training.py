@@ -78,19 +78,29 @@ def _pad_channels(t, mult=8):
     return out
 
 
-def _conv(x, wp, shift, cin, cout, k, stride, cdt, odt):
+def _conv(x, wp, shift, cin, cout, k, stride, cdt, odt, residual=None):
     b, h, w, _ = x.shape
     oh, ow = (h, w) if stride == 1 else ((h + 1 - k) // 2 + 1, (w + 1 - k) // 2 + 1)
     y = _empty((b, oh, ow, cout), x, odt)
     code = _lib.dtype_code(cdt)
-    _lib.launch("ymx_conv2d_fused_ex", x, _lib.ptr(x), _lib.ptr(wp), None, _lib.ptr(shift), None, _lib.ptr(y), b, h, w, cin, cout,
+    _lib.launch("ymx_conv2d_fused_ex", x, _lib.ptr(x), _lib.ptr(wp), None, _lib.ptr(shift), _lib.ptr(residual), _lib.ptr(y), b, h, w, cin, cout,
                 k, stride, _lib.ACT_NONE, code, _lib.dtype_code(x.dtype), _lib.dtype_code(odt), 0, 0, 0)
     return y
 
 
+class GradLink(object):
+    """Joins the two blocks of a ResidialBlock in the backward pass: the block that adds the
+    shortcut leaves the shortcut's gradient (its dy) here instead of handing it to autograd,
+    and the block that produced the shortcut's source adds it inside its input-gradient
+    convolution (the kernel's shortcut input), so x + f(x) costs no separate addition."""
+
+    def __init__(self):
+        self.pending = None
+
+
 class _ConvBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, kernel, bias, shortcut, layer):
+    def forward(ctx, x, kernel, bias, shortcut, layer, link=None):
         cdt = layer.compute_dtype or x.dtype
         if cdt != torch.bfloat16:
             raise ValueError("yolo_amd.training: back-propagation is provided for bfloat16 networks")
@@ -114,6 +124,7 @@ class _ConvBlock(torch.autograd.Function):
         ctx.has_shortcut = shortcut is not None
         ctx.shortcut_dtype = None if shortcut is None else shortcut.dtype
         ctx.x_dtype = x_dtype_in
+        ctx.link = link
         return y
 
     @staticmethod
@@ -185,7 +196,12 @@ class _ConvBlock(torch.autograd.Function):
                     raise ValueError("yolo_amd.training: stride-2 convolutions are 3x3")
                 src = torch.zeros((b, h, w, coutp), device=x.device, dtype=cdt)       # dz on the even rows / columns
                 src[:, 0:2 * oh:2, 0:2 * ow:2] = dzp
-            dx = _conv(src, wdp, None, coutp, cin, k, 1, cdt, cdt)
+            res = None
+            if ctx.link is not None and not ctx.has_shortcut:
+                res, ctx.link.pending = ctx.link.pending, None        # the shortcut's gradient, left by the block after this one
+                if res is not None and (res.dtype != cdt or tuple(res.shape) != (b, h, w, cin)):
+                    raise RuntimeError("yolo_amd.training: shortcut gradient does not match the block's input")
+            dx = _conv(src, wdp, None, coutp, cin, k, 1, cdt, cdt, residual=res)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
         if ctx.needs_input_grad[1]:
@@ -196,18 +212,21 @@ class _ConvBlock(torch.autograd.Function):
                 dkernel = dkernel.contiguous()
         dshortcut = None
         if ctx.has_shortcut and ctx.needs_input_grad[3]:
-            dshortcut = dy.to(ctx.shortcut_dtype)
-        return dx, dkernel, dbias, dshortcut, None
+            if ctx.link is not None and ctx.shortcut_dtype == cdt:
+                ctx.link.pending = dy                                  # added by the first block's input gradient
+            else:
+                dshortcut = dy.to(ctx.shortcut_dtype)
+        return dx, dkernel, dbias, dshortcut, None, None
 
 
-def conv_block(layer, x, shortcut=None):
+def conv_block(layer, x, shortcut=None, link=None):
     """YOLOConv forward that autograd can differentiate (called by YOLOConv.forward inside
-    ``backprop()``)."""
+    ``backprop()``).  link: the GradLink of the ResidialBlock the layer belongs to."""
     if layer.batch_normalization:
         raise ValueError("yolo_amd.training: batch normalisation in training mode is not provided")
     if layer.act_fn is not None:
         raise ValueError("yolo_amd.training: callable activations are not differentiated")
-    return _ConvBlock.apply(x, layer.kernel, layer.bias, shortcut, layer)
+    return _ConvBlock.apply(x, layer.kernel, layer.bias, shortcut, layer, link)
 
 
 class _UpsampleConcat(torch.autograd.Function):
