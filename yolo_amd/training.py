@@ -207,9 +207,9 @@ class _ConvBlock(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if side is not None:
                 torch.cuda.current_stream(x.device).wait_stream(side)
-            dkernel = dwp[:, :, :cin, :cout]
-            if dkernel.shape != dwp.shape:
-                dkernel = dkernel.contiguous()
+            # (handed over as it is where nothing was padded: autograd keeps a tensor that is not a
+            # view as the parameter's .grad without copying it)
+            dkernel = dwp if (cinp == cin and coutp == cout) else dwp[:, :, :cin, :cout].contiguous()
         dshortcut = None
         if ctx.has_shortcut and ctx.needs_input_grad[3]:
             if ctx.link is not None and ctx.shortcut_dtype == cdt:
