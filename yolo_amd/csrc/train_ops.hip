@@ -683,6 +683,17 @@ __device__ __forceinline__ void lds_issue_tr4(unsigned a0, unsigned a1, unsigned
                  : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
                  : "memory");
 }
+__device__ __forceinline__ void lds_issue_tr2(unsigned a0, unsigned a1, uint2 *r) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\t"
+                 "ds_read_b64_tr_b16 %1, %3"
+                 : "=&v"(r[0]), "=&v"(r[1])
+                 : "v"(a0), "v"(a1)
+                 : "memory");
+}
+template <int OUTSTANDING>
+__device__ __forceinline__ void lds_wait_frags2(uint2 *r) {     // r[0..1] are valid after this
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(r[0]), "+v"(r[1]) : "n"(OUTSTANDING) : "memory");
+}
 template <int OUTSTANDING>
 __device__ __forceinline__ void lds_wait_frags(uint2 *r) {      // r[0..3] are valid after this
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(OUTSTANDING) : "memory");
@@ -696,7 +707,6 @@ conv_wgrad_slab_kernel(const WgradSlabArgs sa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wci = wave & 1, wco = wave >> 1;
     const int tile_ci = blockIdx.x % a.n_ci_tiles, tile_co = blockIdx.x / a.n_ci_tiles;
     const int ci0 = tile_ci * 64, co0 = tile_co * 64;
     const int c_begin = blockIdx.z * a.chunks_per_split;        // steps of 32 pixels
@@ -730,30 +740,31 @@ conv_wgrad_slab_kernel(const WgradSlabArgs sa) {
         lds_dma16(zrsrc, dz0 + (unsigned)(stage * 4096 + wave * 1024), off);
     };
 
-    f32x4_t acc[9][2][2];
+    // wave w = input channels 16 w .. 16 w + 15 of the tile x all 64 output channels x 9 taps: the
+    // x fragment, which is read once per tap, is a single 16-channel block per wave, and the dz
+    // fragments (four blocks), read once per step, serve all nine taps
+    f32x4_t acc[9][4];
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[tp][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[tp][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // transposed-read geometry: this lane supplies the addresses of pixel rows r0 and r0 + 4 of the step
     const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int r0 = 8 * g + q4;
-    unsigned ablk[9][2];                                         // LDS address of (tap, channel block) inside slab row 0
+    unsigned ablk[9];                                            // LDS address of (tap, this wave's channel block) inside slab row 0
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
         const int shift = (tp / 3 - 1) * W + (tp % 3 - 1);
         const int key = (r0 + shift) & 3;                        // steps start at multiples of 32: the key does not move
-#pragma unroll
-        for (int i = 0; i < 2; ++i) ablk[tp][i] = lds0 + (unsigned)((((wci * 2 + i) ^ key) * 32) + p4 * 8);
+        ablk[tp] = lds0 + (unsigned)(((wave ^ key) * 32) + p4 * 8);
     }
-    const unsigned boff0 = (unsigned)(r0 * 128 + (((wco * 2) ^ (r0 & 3)) * 32) + p4 * 8);
-    const unsigned boff1 = (unsigned)(r0 * 128 + (((wco * 2 + 1) ^ (r0 & 3)) * 32) + p4 * 8);
+    unsigned boff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) boff[j] = (unsigned)(r0 * 128 + ((j ^ (r0 & 3)) * 32) + p4 * 8);
 
-    // a wave whose 32 x 32 channels all lie beyond the layer's (the first layer has 8 x 32) only moves data
-    const bool live = __builtin_amdgcn_readfirstlane((ci0 + wci * 32 < a.Cin && co0 + wco * 32 < a.Cout) ? 1 : 0) != 0;
+    // a wave whose 16 input channels all lie beyond the layer's (the first layer has 8) only moves data
+    const bool live = __builtin_amdgcn_readfirstlane((ci0 + wave * 16 < a.Cin) ? 1 : 0) != 0;
 
     // ---- prologue: the slab up to the frontier of step c_begin + D - 1, the dz rows of those steps ----
     if (t < 32) ((float *)(smem + RX * 128 + WS_NS * 4096))[t] = 0.0f;
@@ -802,33 +813,33 @@ conv_wgrad_slab_kernel(const WgradSlabArgs sa) {
             if (tc == 2) { ok0 = ok0 && right[0]; ok1 = ok1 && right[1]; }
             const unsigned ra = ok0 ? ((pb0 + shift_b) & ring_mask) : zrow - lds0;     // ablk carries lds0
             const unsigned rb = ok1 ? ((pb1 + shift_b) & ring_mask) : zrow - lds0;
-            lds_issue_tr4(ra + ablk[tp][0], rb + ablk[tp][0], ra + ablk[tp][1], rb + ablk[tp][1], r);
+            lds_issue_tr2(ra + ablk[tp], rb + ablk[tp], r);
         };
-        uint2 rb4[4], ra4[3][4];
-        lds_issue_tr4(zb + boff0, zb + boff0 + 512, zb + boff1, zb + boff1 + 512, rb4);
-        issue_tap(0, ra4[0]);
-        issue_tap(1, ra4[1]);
+        uint2 rb8[8], ra2[3][2];
+        lds_issue_tr4(zb + boff[0], zb + boff[0] + 512, zb + boff[1], zb + boff[1] + 512, rb8);
+        lds_issue_tr4(zb + boff[2], zb + boff[2] + 512, zb + boff[3], zb + boff[3] + 512, rb8 + 4);
+        issue_tap(0, ra2[0]);
+        issue_tap(1, ra2[1]);
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
             // the reads of the next two taps travel while this tap's products are formed
             if (tp < 7) {
-                issue_tap(tp + 2, ra4[(tp + 2) % 3]);
-                if (tp == 0) lds_wait_frags<8>(rb4);
-                lds_wait_frags<8>(ra4[tp % 3]);
+                issue_tap(tp + 2, ra2[(tp + 2) % 3]);
+                if (tp == 0) { lds_wait_frags<4>(rb8); lds_wait_frags<4>(rb8 + 4); }
+                lds_wait_frags2<4>(ra2[tp % 3]);
             } else if (tp == 7) {
-                lds_wait_frags<4>(ra4[tp % 3]);
+                lds_wait_frags2<2>(ra2[tp % 3]);
             } else {
-                lds_wait_frags<0>(ra4[tp % 3]);
+                lds_wait_frags2<0>(ra2[tp % 3]);
             }
-            const uint2 *r = ra4[tp % 3];
-            const uint4 fa[2] = {make_uint4(r[0].x, r[0].y, r[1].x, r[1].y), make_uint4(r[2].x, r[2].y, r[3].x, r[3].y)};
-            const uint4 fb[2] = {make_uint4(rb4[0].x, rb4[0].y, rb4[1].x, rb4[1].y), make_uint4(rb4[2].x, rb4[2].y, rb4[3].x, rb4[3].y)};
+            const uint2 *r = ra2[tp % 3];
+            const uint4 fa = make_uint4(r[0].x, r[0].y, r[1].x, r[1].y);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[i]),
-                                                                             __builtin_bit_cast(bf16x8_t, fb[j]), acc[tp][i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                const uint4 fb = make_uint4(rb8[2 * j].x, rb8[2 * j].y, rb8[2 * j + 1].x, rb8[2 * j + 1].y);
+                acc[tp][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa), __builtin_bit_cast(bf16x8_t, fb),
+                                                                     acc[tp][j], 0, 0, 0);
+            }
         }
         }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * 2) : "memory");   // the next step's rows (this wave's part) have landed
@@ -841,15 +852,13 @@ conv_wgrad_slab_kernel(const WgradSlabArgs sa) {
     for (int tp = 0; tp < 9; ++tp) {
         float *out = a.out + ((size_t)blockIdx.z * 9 + tp) * a.Cin * a.Cout;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ci = ci0 + wci * 32 + i * 16 + 4 * (lane >> 4) + r;
-                    const int co = co0 + wco * 32 + j * 16 + (lane & 15);
-                    if (ci < a.Cin && co < a.Cout) out[(size_t)ci * a.Cout + co] = acc[tp][i][j][r];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + wave * 16 + 4 * (lane >> 4) + r;
+                const int co = co0 + j * 16 + (lane & 15);
+                if (ci < a.Cin && co < a.Cout) out[(size_t)ci * a.Cout + co] = acc[tp][j][r];
+            }
     }
 }
 
