@@ -699,6 +699,13 @@ __device__ __forceinline__ void lds_wait_frags(uint2 *r) {      // r[0..3] are v
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(OUTSTANDING) : "memory");
 }
 
+// Chunk swizzle of the 128-byte rows: a transposing read is served in two groups of 32 lanes,
+// i.e. rows s + {0..3} and s + {8..11} (s arbitrary: a tap shifts the rows), over 64 banks of
+// 4 bytes.  Rows of equal parity share a half of the banks, so the four such rows of a group
+// (s, s + 2, s + 8, s + 10 and the odd ones likewise) must put their 32-byte chunk in four
+// different places: bit 1 and bit 3 of the row number tell them apart for every s.
+__device__ __forceinline__ int ws_key(int row) { return ((row >> 1) & 1) | ((row >> 2) & 2); }
+
 __global__ void __launch_bounds__(256, 2)
 conv_wgrad_slab_kernel(const WgradSlabArgs sa) {
     const WgradArgs &a = sa.w;
@@ -724,7 +731,7 @@ conv_wgrad_slab_kernel(const WgradSlabArgs sa) {
     const int d_rl = lane >> 3, d_sl = lane & 7;
     auto issue_x_group = [&](int gi) {                           // input pixels 8 gi .. 8 gi + 7
         const int pi = gi * 8 + d_rl;
-        const int pair = (d_sl >> 1) ^ (pi & 3);
+        const int pair = (d_sl >> 1) ^ ws_key(pi);
         const int ci = ci0 + (pair * 2 + (d_sl & 1)) * 8;
         unsigned off = OOB;
         if (pi >= 0 && pi < a.P && ci < a.Cin) off = (unsigned)((pi * a.x_ld + ci) * 2);
@@ -733,7 +740,7 @@ conv_wgrad_slab_kernel(const WgradSlabArgs sa) {
     auto issue_dz = [&](int step, int stage) {                   // this wave's eight rows of the step's 32
         const int row = wave * 8 + d_rl;
         const int p = step * 32 + row;
-        const int pair = (d_sl >> 1) ^ (row & 3);
+        const int pair = (d_sl >> 1) ^ ws_key(row);
         const int co = co0 + (pair * 2 + (d_sl & 1)) * 8;
         unsigned off = OOB;
         if (step < c_end && p < a.P && co < a.Cout) off = (unsigned)((p * a.dz_ld + co) * 2);
@@ -752,16 +759,19 @@ conv_wgrad_slab_kernel(const WgradSlabArgs sa) {
     // transposed-read geometry: this lane supplies the addresses of pixel rows r0 and r0 + 4 of the step
     const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int r0 = 8 * g + q4;
-    unsigned ablk[9];                                            // LDS address of (tap, this wave's channel block) inside slab row 0
+    unsigned ablk[9][2];                                         // LDS address of (tap, pixel row r0 / r0 + 4, this wave's block) inside slab row 0
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
         const int shift = (tp / 3 - 1) * W + (tp % 3 - 1);
-        const int key = (r0 + shift) & 3;                        // steps start at multiples of 32: the key does not move
-        ablk[tp] = lds0 + (unsigned)(((wave ^ key) * 32) + p4 * 8);
-    }
-    unsigned boff[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) boff[j] = (unsigned)(r0 * 128 + ((j ^ (r0 & 3)) * 32) + p4 * 8);
+        for (int h = 0; h < 2; ++h)                              // steps start at multiples of 32: the key does not move
+            ablk[tp][h] = lds0 + (unsigned)(((wave ^ ws_key(r0 + 4 * h + shift)) * 32) + p4 * 8);
+    }
+    unsigned boff[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) boff[j][h] = (unsigned)((r0 + 4 * h) * 128 + ((j ^ ws_key(r0 + 4 * h)) * 32) + p4 * 8);
 
     // a wave whose 16 input channels all lie beyond the layer's (the first layer has 8) only moves data
     const bool live = __builtin_amdgcn_readfirstlane((ci0 + wave * 16 < a.Cin) ? 1 : 0) != 0;
@@ -813,11 +823,11 @@ conv_wgrad_slab_kernel(const WgradSlabArgs sa) {
             if (tc == 2) { ok0 = ok0 && right[0]; ok1 = ok1 && right[1]; }
             const unsigned ra = ok0 ? ((pb0 + shift_b) & ring_mask) : zrow - lds0;     // ablk carries lds0
             const unsigned rb = ok1 ? ((pb1 + shift_b) & ring_mask) : zrow - lds0;
-            lds_issue_tr2(ra + ablk[tp], rb + ablk[tp], r);
+            lds_issue_tr2(ra + ablk[tp][0], rb + ablk[tp][1], r);
         };
         uint2 rb8[8], ra2[3][2];
-        lds_issue_tr4(zb + boff[0], zb + boff[0] + 512, zb + boff[1], zb + boff[1] + 512, rb8);
-        lds_issue_tr4(zb + boff[2], zb + boff[2] + 512, zb + boff[3], zb + boff[3] + 512, rb8 + 4);
+        lds_issue_tr4(zb + boff[0][0], zb + boff[0][1], zb + boff[1][0], zb + boff[1][1], rb8);
+        lds_issue_tr4(zb + boff[2][0], zb + boff[2][1], zb + boff[3][0], zb + boff[3][1], rb8 + 4);
         issue_tap(0, ra2[0]);
         issue_tap(1, ra2[1]);
 #pragma unroll
