@@ -66,6 +66,17 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"op 0" in L.ymx_last_error() and b"min_tiles" in L.ymx_last_error()
     prog[0].kind = 7
     assert L.ymx_run_program(prog, 1, None) == -1 and b"unknown kind" in L.ymx_last_error()
+    # the backward-pass entry points
+    assert L.ymx_conv_wgrad(None, 0, one, 0, one, 1, 8, 8, 8, 8, 3, 1, None, 0, None) == -1
+    assert L.ymx_conv_wgrad(one, 0, one, 0, one, 1, 8, 8, 12, 8, 3, 1, None, 0, None) == -2 and b"multiples of 8" in L.ymx_last_error()
+    assert L.ymx_conv_wgrad(one, 0, one, 0, one, 1, 8, 8, 8, 8, 5, 1, None, 0, None) == -2
+    nb = L.ymx_conv_wgrad_workspace_bytes(64, 52, 52, 512, 1024, 3, 1)
+    assert nb > 0 and nb % (9 * 512 * 1024 * 4) == 0                     # whole partial gradients, one per pixel slice
+    assert L.ymx_conv_wgrad(one, 0, one, 0, one, 64, 52, 52, 512, 1024, 3, 1, one, 16, None) == -3
+    assert L.ymx_pack_weights_dgrad(one, one, 3, 64, 255, 248, _lib.BF16, None) == -1 and b"dz_channels" in L.ymx_last_error()
+    assert L.ymx_pack_weights_dgrad(None, one, 3, 64, 256, 256, _lib.BF16, None) == -1
+    assert L.ymx_set_option(b"wgrad_variant", 3) == -1
+    assert L.ymx_set_option(b"wgrad_variant", 2) == 0 and L.ymx_set_option(b"wgrad_variant", 0) == 0
 
 
 def test_module_interface_matches_reference():
