@@ -564,7 +564,7 @@ def main():
     valid_mean = float(out[3].float().mean().item())
 
     line = {
-        "metric": "images/sec (fwd+decode+NMS) at 416^2",
+        "metric": "images/sec (fwd+decode+NMS) at %d^2" % S,
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
