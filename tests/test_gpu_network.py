@@ -455,6 +455,54 @@ def test_concurrent_sub_batches_equal_whole_batch():
             assert torch.equal(u[:2], v)
 
 
+def test_decode_beside_matrix_kernels_screen():
+    """Bounded screen for results that depend on what else runs on the GPU.  The decode+filter
+    launch is repeated on one stream while a second stream keeps the matrix pipes busy (a
+    hipBLASLt matmul and small convolutions, which leave room on their CUs for decode
+    workgroups); every launch must give the bits of a launch that ran alone.  Then 40 forwards
+    of a batch cut into concurrent sub-batches against the whole-batch program.  (A build of
+    the decode kernel with hipcc's packed-FMA box corners failed 112 of 300 such launches and
+    about one forward in one.)"""
+    from yolo_amd import Detector
+    from yolo_amd.layers import YOLOConv
+    C = 80
+    x = _image(7, 160).to(DEV)
+    whole = Detector(num_classes=C, dtype=torch.bfloat16, seed=5, split="off").to(DEV)
+    whole.calibrate_(x[:2].contiguous())
+    want = whole(x)
+    want = [t.clone() for t in want] + [want.keep_idx.clone()]
+    part = whole._plan(7, 160, x.dtype, x.device).parts[0]
+    part.boxes.zero_()
+    whole._decode_part(part, 160)
+    torch.cuda.synchronize()
+    ref_boxes, ref_counts, ref_src = part.boxes.clone().view(torch.int32), part.counts.clone(), part.src_idx.clone()
+    ma = torch.randn(2048, 2048, device=DEV).bfloat16()
+    conv = YOLOConv((3, 3, 1024), dtype=torch.bfloat16, in_channels=512).to(DEV)
+    cx = torch.randn(4, 20, 20, 512, device=DEV).bfloat16()
+    conv(cx)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    bad = torch.zeros((), device=DEV, dtype=torch.int32)
+    n = int(ref_counts.max())
+    for i in range(150):
+        with torch.cuda.stream(sb):
+            for _ in range(2):
+                torch.matmul(ma, ma) if i % 2 else conv(cx)
+        with torch.cuda.stream(sa):
+            whole._decode_part(part, 160)
+            bad += ((part.boxes.view(torch.int32) != ref_boxes).any() | (part.counts != ref_counts).any() |
+                    (part.src_idx[:, :n] != ref_src[:, :n]).any()).int()
+    torch.cuda.synchronize()
+    assert int(bad) == 0
+    for cut in ((4, 3), (5, 2)):
+        det = Detector(num_classes=C, dtype=torch.bfloat16, seed=5, split=cut).to(DEV)
+        det.calibrate_(x[:2].contiguous())
+        for _ in range(20):
+            got = det(x)
+            for u, v in zip(want, list(got) + [got.keep_idx]):
+                assert torch.equal(u, v)
+
+
 def test_auto_cut_is_timed_once_and_exact():
     """split="auto" on a batch large enough to be cut: whichever cut the timing picks, the
     results equal the whole-batch program, and the choice is cached per input shape."""

@@ -429,3 +429,25 @@ def test_to_tfrecord_shards(tmp_path):
     np.testing.assert_array_equal(T.parse_tensor(f["small_targets"]), np.argwhere(examples[0][1][0][0] != 0))
     with pytest.raises(ValueError):
         T.to_tfrecord(examples[:2], str(tmp_path / "x"), 3)
+
+
+def test_library_code_has_no_packed_fma_of_the_hazardous_form():
+    """gfx950 returns a packed fp32 FMA without its addend on lanes 32-63, while another wave's
+    MFMAs occupy the SIMD, when the multiplier is a scalar pair and the low result's addend is
+    taken from the high register (tools/isa_lint.py says how that was measured).  hipcc forms
+    that instruction on its own from scalar code, so the built library's machine code is what is
+    checked: every kernel, disassembled."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_lint
+    from yolo_amd import _lib
+    # the matcher itself, on the instruction as hipcc emitted it and on its harmless relatives
+    bad = "v_pk_fma_f32 v[14:15], s[12:13], v[16:17], v[12:13] op_sel:[0,0,1] op_sel_hi:[0,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]"
+    assert isa_lint.hazardous(bad)
+    assert isa_lint.hazardous("v_pk_fma_f32 v[2:3], v[4:5], s[6:7], v[8:9] op_sel:[0,0,1] op_sel_hi:[1,0,1]")
+    assert not isa_lint.hazardous("v_pk_fma_f32 v[14:15], s[12:13], v[16:17], v[12:13] op_sel_hi:[0,1,1]")
+    assert not isa_lint.hazardous("v_pk_fma_f32 v[14:15], v[20:21], v[16:17], v[12:13] op_sel:[0,0,1] op_sel_hi:[0,1,0]")
+    assert not isa_lint.hazardous("v_pk_mul_f32 v[12:13], s[92:93], v[12:13] op_sel:[0,1]")
+    assert not isa_lint.hazardous("v_fma_f32 v1, s2, v3, v4")
+    found, functions = isa_lint.scan(_lib.LIB_PATH)
+    assert functions >= 100, functions          # the disassembly really covered the kernels
+    assert found == [], found
