@@ -44,7 +44,10 @@ const char *ymx_last_error(void);
 /* Tuning knobs (no counterpart in the reference).  They are PER CALLING THREAD: a thread
  * that sets one changes only its own later calls, every thread starts from the defaults, and
  * the library keeps no other mutable state besides the thread-local error string (kernel
- * attributes it sets once per device are idempotent).  "dma_min_tiles": the fewest 256x256
+ * attributes it sets once per device are idempotent).  Mind frameworks that launch from threads
+ * of their own: torch.autograd runs backward() on a worker thread, so an option set on the
+ * thread that calls backward() does not reach the launches made inside it (the Python side
+ * sets yolo_amd.training.options instead, which are applied on the launching thread).  "dma_min_tiles": the fewest 256x256
  * output tiles for which a bf16 convolution with more than 128 output channels runs on the
  * large-tile LDS-DMA kernel instead of the 128x128 kernel (default 160; 0 forces it, a huge
  * value disables it; ymx_op.min_tiles overrides it per op).  "dma_variant": which large-tile
@@ -328,6 +331,11 @@ int ymx_bias_grad(const void *dz, long long n_pix, int C, int ld, int dtype, flo
 size_t ymx_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride);
 int ymx_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw, int B, int H, int W,
                    int Cin, int Cout, int k, int stride, void *workspace, size_t ws_bytes, void *stream);
+/* Which kernel ymx_conv_wgrad would take for dense tensors of this shape under the calling
+ * thread's "wgrad_variant": "wgrad_slab" (all taps from one resident slab), "wgrad_dma" (per
+ * tap, LDS-DMA) or "wgrad_reg" (per tap, register-staged); NULL on a bad shape.  No counterpart
+ * in the reference; for tests and tuning tools. */
+const char *ymx_conv_wgrad_kernel_label(int B, int H, int W, int Cin, int Cout, int k, int stride);
 int ymx_upsample2x_backward(const void *dy, void *dx, int B, int H, int W, int C, int dy_ld, int c_off,
                             int dtype, void *stream);
 /* Packs, straight from the forward HWIO fp32 kernel [k][k][Cin][Cout], the kernel of the
@@ -386,6 +394,13 @@ int ymx_assign_labels(const float *boxes, const int *counts, int B, int max_boxe
  * (tf.math.divide_no_nan). */
 int ymx_bbox_iou(const float *b1, const float *b2, float *out, long long n, int giou,
                  void *stream);
+
+/* ---- CRC-32C of a host buffer ---------------------------------------------------
+ * The checksum of TFRecord framing (to_tfrecord, dataset.py:64-126, writes through
+ * tf.io.TFRecordWriter): Castagnoli polynomial, reflected, initial value and final xor
+ * 0xFFFFFFFF; crc = the checksum of the bytes before `data` (0 for none), so a buffer can be
+ * fed in pieces.  Host memory, no device work. */
+unsigned ymx_crc32c(const void *data, size_t n, unsigned crc);
 
 #ifdef __cplusplus
 }

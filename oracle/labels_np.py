@@ -56,6 +56,13 @@ def preprocess_true_boxes(bboxes, input_size, num_classes, strides, anchors_grid
     for bbox in np.asarray(bboxes, np.float64):
         coor = bbox[:4]
         cls = int(bbox[4])
+        # Build-defined: a box whose class is outside [0, C) or whose centre cell lies outside the
+        # grid on any scale is skipped whole (the reference's numpy indexing raises IndexError, or
+        # silently wraps a negative index); ymx_assign_labels does the same.
+        ctr = (coor[2:] + coor[:2]) * 0.5
+        cells = [np.floor(ctr / s) for s in strides]
+        if not (0 <= cls < num_classes) or any((c < 0).any() or (c >= sizes[i]).any() for i, c in enumerate(cells)):
+            continue
         onehot = np.zeros(num_classes)
         onehot[cls] = 1.0
         smooth = onehot * (1 - 0.01) + 0.01 * np.full(num_classes, 1.0 / num_classes)        # :419-423

@@ -79,15 +79,21 @@ def test_conv_block_gradients(case):
     # the same gradient
     from yolo_amd import _lib
     g_auto = layer.kernel.grad.clone()
-    for variant in (1, 2):
+    # (backward() runs on autograd's own thread and libymx options are per thread, so the variant
+    # goes through training.options, which the backward step applies where it launches; the
+    # trace shows which kernel each run really took)
+    for variant, label in ((1, "wgrad_reg"), (2, "wgrad_dma")):
         layer.kernel.grad = None
+        T.trace = []
         try:
-            _lib.check(_lib.lib().ymx_set_option(b"wgrad_variant", variant))
+            T.options["wgrad_variant"] = variant
             with T.backprop():
                 y2 = layer(xg.detach(), residual=None if scg is None else scg.detach())
             (y2.float() * G.to(DEV)).sum().backward()
+            assert T.trace == [label], T.trace
         finally:
-            _lib.check(_lib.lib().ymx_set_option(b"wgrad_variant", 0))
+            T.options["wgrad_variant"] = 0
+            T.trace = None
         assert _scaled_err(layer.kernel.grad.cpu(), po["kernel"].grad) < 1e-2
         assert _scaled_err(layer.kernel.grad.cpu(), g_auto.cpu()) < 1e-5          # same products, another summation order
     # outside the context nothing is recorded and the fused inference kernels run

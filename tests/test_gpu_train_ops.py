@@ -156,6 +156,9 @@ def test_assign_labels_vs_oracle(C, size, literal):
     for b in range(B):
         boxes[b, :counts[b]] = _random_boxes(rng, counts[b], size, C)
     boxes[0, 5] = boxes[0, 4]                                  # an exact duplicate: the later one overwrites
+    boxes[3, 2] = [size + 40, 10, size + 90, 60, 0]            # centre right of the image: skipped whole (no label, no ring slot)
+    boxes[3, 7] = [-80, 20, -10, 90, 0]                        # centre left of the image
+    boxes[4, 1, 4] = C                                         # class out of range: skipped
     cfg = Y.config
     ag = DS.scale_anchors(literal=literal)
     np.testing.assert_array_equal(ag, LB.scale_anchors(cfg["anchors"], cfg["strides"], literal).astype(np.float32))

@@ -365,6 +365,15 @@ def test_tfrecord_format():
     assert T.crc32c(b"\xff" * 32) == 0x62A8AB43
     assert T.crc32c(bytes(range(32))) == 0x46DD794E
     assert T.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
+    # the library's eight-bytes-per-step routine against the bytewise definition: every length
+    # around its block size, an unaligned start, and a buffer fed in two pieces
+    from yolo_amd import _lib
+    blob = bytes(np.random.default_rng(0).integers(0, 256, 5000, dtype=np.uint8))
+    for n in list(range(0, 40)) + [63, 64, 65, 1000, 4999, 5000]:
+        assert int(_lib.lib().ymx_crc32c(blob[:n], n, 0)) == T._crc32c_bytewise(blob[:n]), n
+        assert T.crc32c(blob[3:3 + n]) == T._crc32c_bytewise(blob[3:3 + n])
+    part = int(_lib.lib().ymx_crc32c(blob[:1234], 1234, 0))
+    assert int(_lib.lib().ymx_crc32c(blob[1234:], len(blob) - 1234, part)) == T._crc32c_bytewise(blob)
     c = T.crc32c(b"abc")
     assert T.masked_crc32c(b"abc") == (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
     # wire encoding by hand: Example{features{feature{"a": float_list [1.0]}}}

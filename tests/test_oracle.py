@@ -482,3 +482,19 @@ def test_loss_torch_restatement_matches_numpy_and_finite_differences():
             vals.append(g2 + c2 + p2)
         fd = (vals[0] - vals[1]) / (2 * h)
         assert abs(fd - grad.reshape(-1)[i]) <= 1e-5 + 1e-4 * abs(fd), (i, fd, grad.reshape(-1)[i])
+
+
+def test_labels_oracle_skips_boxes_without_a_cell():
+    """Build-defined: a box centred outside the image, or of a class outside [0, C), leaves no
+    label row and takes no slot of the ground-truth ring (the reference raises or wraps)."""
+    from oracle import labels_np as LB
+    from oracle import postproc_np as P
+    ag = LB.scale_anchors(P.ANCHORS, P.STRIDES, False)
+    inside = np.array([[100.0, 120.0, 180.0, 200.0, 1.0]])
+    want = LB.preprocess_true_boxes(inside, 416, 3, P.STRIDES, ag)
+    mixed = np.array([[430.0, 10.0, 470.0, 60.0, 0.0], [100.0, 120.0, 180.0, 200.0, 1.0], [-90.0, 5.0, -10.0, 40.0, 2.0],
+                      [10.0, 10.0, 50.0, 50.0, 3.0], [10.0, 10.0, 50.0, 50.0, -1.0]])
+    got = LB.preprocess_true_boxes(mixed, 416, 3, P.STRIDES, ag)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+    assert sum(float(np.abs(w).sum()) for w in want) > 0

@@ -40,8 +40,7 @@ def main():
     C = 80
     cfg = Y.config
     if os.environ.get("WGRAD"):
-        from yolo_amd import _lib
-        _lib.check(_lib.lib().ymx_set_option(b"wgrad_variant", int(os.environ["WGRAD"])))
+        T.options["wgrad_variant"] = int(os.environ["WGRAD"])      # applied on autograd's thread, where the launches happen
     det = Y.Detector(num_classes=C, dtype=torch.bfloat16, seed=0).to(DEV)
     x = torch.rand(B, size, size, 3, device=DEV)
     det.calibrate_(x[:2].contiguous())

@@ -68,6 +68,8 @@ SIGNATURES = {
     "ymx_bias_grad": (_i, [_vp, ctypes.c_longlong, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ymx_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "ymx_conv_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "ymx_crc32c": (ctypes.c_uint, [ctypes.c_char_p, _sz, ctypes.c_uint]),
+    "ymx_conv_wgrad_kernel_label": (ctypes.c_char_p, [_i] * 7),
     "ymx_upsample2x_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ymx_letterbox": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "ymx_draw_boxes": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),

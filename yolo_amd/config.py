@@ -1,11 +1,8 @@
-"""Loads config.yml next to this file (as the reference's config.py:1-9 does)."""
-import os
+"""The constants table: ``config`` is the parsed yolo_amd/config.yml (anchors, strides, xyscale,
+anchors per scale, IoU loss threshold), the same data the reference reads at import
+(/root/reference/config.py:1-9, /root/reference/config.yml:1-7)."""
+import pathlib
 
 import yaml
 
-config_path = os.path.join(os.path.dirname(__file__), "config.yml")
-try:
-    with open(config_path) as f:
-        config = yaml.safe_load(f)
-except FileNotFoundError:
-    raise FileNotFoundError("Config file not found.")
+config = yaml.safe_load((pathlib.Path(__file__).parent / "config.yml").read_text())

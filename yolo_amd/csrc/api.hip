@@ -517,6 +517,48 @@ int ymx_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw
     return launch_conv_wgrad(x, x_ld, dz, dz_ld, dw, B, H, W, Cin, Cout, k, stride, workspace, (hipStream_t)stream);
 }
 
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), eight bytes per step: host code, for
+// the record framing of yolo_amd/tfrecord.py (records hold megabytes of tensor data).
+unsigned ymx_crc32c(const void *data, size_t n, unsigned crc) {
+    static unsigned table[8][256];
+    static std::atomic<int> ready{0};
+    if (!ready.load(std::memory_order_acquire)) {
+        unsigned t[8][256];
+        for (unsigned i = 0; i < 256; ++i) {
+            unsigned c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            t[0][i] = c;
+        }
+        for (unsigned i = 0; i < 256; ++i)
+            for (int k = 1; k < 8; ++k) t[k][i] = t[0][t[k - 1][i] & 0xffu] ^ (t[k - 1][i] >> 8);
+        memcpy(table, t, sizeof(t));             // every thread writes the same values
+        ready.store(1, std::memory_order_release);
+    }
+    const unsigned char *p = (const unsigned char *)data;
+    unsigned c = ~crc;
+    if (!p) return crc;
+    while (n >= 8) {
+        unsigned lo, hi;
+        memcpy(&lo, p, 4);
+        memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = table[7][lo & 0xffu] ^ table[6][(lo >> 8) & 0xffu] ^ table[5][(lo >> 16) & 0xffu] ^ table[4][lo >> 24] ^
+            table[3][hi & 0xffu] ^ table[2][(hi >> 8) & 0xffu] ^ table[1][(hi >> 16) & 0xffu] ^ table[0][hi >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = table[0][(c ^ *p++) & 0xffu] ^ (c >> 8);
+    return ~c;
+}
+
+const char *ymx_conv_wgrad_kernel_label(int B, int H, int W, int Cin, int Cout, int k, int stride) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2)) {
+        fail(YMX_EARG, "conv_wgrad_kernel_label: bad shape");
+        return nullptr;
+    }
+    return conv_wgrad_label(B, H, W, Cin, Cout, k, stride);
+}
+
 int ymx_upsample2x_backward(const void *dy, void *dx, int B, int H, int W, int C, int dy_ld, int c_off, int dtype, void *stream) {
     if (!dy || !dx) return fail(YMX_EARG, "upsample2x_backward: null pointer");
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || c_off < 0) return fail(YMX_EARG, "upsample2x_backward: bad size");

@@ -563,8 +563,17 @@ assign_labels_kernel(const LabelArgs a) {
         double iou[3][3];
         int gx[3], gy[3];
         bool any_pos = false;
+        // a box whose centre lies outside the image has no responsible cell on any scale (the
+        // reference's numpy indexing raises, or wraps a negative index): it is skipped whole --
+        // no label row and no slot in the ground-truth ring
+        bool inside = true;
+        for (int i = 0; i < 3; ++i) {
+            gx[i] = (int)floor(xywh[0] / a.stride[i]);
+            gy[i] = (int)floor(xywh[1] / a.stride[i]);
+            inside = inside && (unsigned)gx[i] < (unsigned)a.S[i] && (unsigned)gy[i] < (unsigned)a.S[i];
+        }
+        if (!inside) continue;
         auto write = [&](int i, int an) {
-            if ((unsigned)gx[i] >= (unsigned)a.S[i] || (unsigned)gy[i] >= (unsigned)a.S[i]) return;
             float *row = a.label[i] + ((((size_t)b * a.S[i] + gy[i]) * a.S[i] + gx[i]) * 3 + an) * D;
             for (int c = lane; c < D; c += 64)
                 row[c] = (float)(c < 4 ? xywh[c] : (c == 4 ? 1.0 : (c - 5 == cls ? hi : lo)));
@@ -577,8 +586,6 @@ assign_labels_kernel(const LabelArgs a) {
         for (int i = 0; i < 3; ++i) {
             const double sx = 1.0 * xywh[0] / a.stride[i], sy = 1.0 * xywh[1] / a.stride[i];
             const double sw = 1.0 * xywh[2] / a.stride[i], sh = 1.0 * xywh[3] / a.stride[i];
-            gx[i] = (int)floor(sx);
-            gy[i] = (int)floor(sy);
             const double cx = gx[i] + 0.5, cy = gy[i] + 0.5;
             bool pos = false;
             for (int an = 0; an < 3; ++an) {
@@ -621,7 +628,8 @@ extern "C" int ymx_assign_labels(const float *boxes, const int *counts, int B, i
     a.boxes = boxes; a.counts = counts; a.B = B; a.nmax = max_boxes; a.C = C;
     for (int i = 0; i < 3; ++i) {
         if (!labels[i] || !gt_boxes[i]) return fail(YMX_EARG, "assign_labels: output %d missing", i);
-        if (!(strides[i] > 0.0f)) return fail(YMX_EARG, "assign_labels: stride %d not positive", i);
+        if (!(strides[i] >= 1.0f) || strides[i] != (float)(int)strides[i])
+            return fail(YMX_EARG, "assign_labels: stride %d must be a whole number >= 1, got %g", i, (double)strides[i]);
         a.label[i] = labels[i]; a.gt[i] = gt_boxes[i];
         a.stride[i] = strides[i];
         a.S[i] = (int)(input_size / (int)strides[i]);

@@ -918,6 +918,15 @@ size_t conv_wgrad_workspace_bytes(int k, int Cin, int Cout, long long P) {
     return splits > 1 ? (size_t)splits * k * k * Cin * Cout * 4 : 0;
 }
 
+// Which of the three weight-gradient kernels launch_conv_wgrad takes for dense tensors of this
+// shape under the calling thread's "wgrad_variant".
+const char *conv_wgrad_label(int B, int H, int W, int Cin, int Cout, int k, int stride) {
+    const int OH = stride == 1 ? H : (H + 1 - k) / 2 + 1, OW = stride == 1 ? W : (W + 1 - k) / 2 + 1;
+    const long long xb = wgrad_bytes((long long)B * H * W, Cin), zb = wgrad_bytes((long long)B * OH * OW, Cout);
+    if (wgrad_use_slab(k, stride, W, xb, zb)) return "wgrad_slab";
+    return wgrad_use_dma(xb, zb) ? "wgrad_dma" : "wgrad_reg";
+}
+
 int launch_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw, int B, int H, int W, int Cin, int Cout, int k,
                       int stride, void *ws, hipStream_t s) {
     WgradArgs a;

@@ -36,12 +36,24 @@ def _table():
     return _TABLE
 
 
-def crc32c(data):
+def _crc32c_bytewise(data):
+    """One table look-up per byte, in Python: the definition, kept for short inputs and as the
+    cross-check of the library routine."""
     t = _table()
     c = 0xFFFFFFFF
     for b in bytes(data):
         c = t[(c ^ b) & 0xFF] ^ (c >> 8)
     return c ^ 0xFFFFFFFF
+
+
+def crc32c(data):
+    """CRC-32C of a bytes-like object.  Records carry megabytes of tensor data, so anything
+    beyond a few bytes goes through libymx's eight-bytes-per-step host routine (ymx_crc32c)."""
+    data = bytes(data)
+    if len(data) < 64:
+        return _crc32c_bytewise(data)
+    from . import _lib
+    return int(_lib.lib().ymx_crc32c(data, len(data), 0))
 
 
 def masked_crc32c(data):

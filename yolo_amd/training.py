@@ -51,6 +51,22 @@ class backprop(object):
         return False
 
 
+# Tuning options (names of ymx_set_option) for the launches of the backward pass.  libymx keeps
+# its options per calling thread and torch.autograd runs backward() on a worker thread of its
+# own, so an option set by the caller's thread never reaches those launches: they are listed
+# here instead and applied by the backward step itself, on whatever thread it runs on.
+options = {}
+# If set to a list, every weight-gradient launch of the backward pass appends the label of the
+# kernel it takes (ymx_conv_wgrad_kernel_label): what tests and timing tools read.
+trace = None
+
+
+def _apply_options():
+    L = _lib.lib()
+    for name, value in options.items():
+        _lib.check(L.ymx_set_option(name.encode(), int(value)))
+
+
 overlap_wgrad = True        # weight gradients on a second HIP stream, next to the input gradients
 _side = {}
 
@@ -139,6 +155,7 @@ class _ConvBlock(torch.autograd.Function):
         oh, ow = z.shape[1], z.shape[2]
         dy = dy.to(cdt).contiguous()
         L = _lib.lib()
+        _apply_options()
         npix = b * oh * ow
         dbias = None
         if layer.act_code != _lib.ACT_NONE:
@@ -170,6 +187,8 @@ class _ConvBlock(torch.autograd.Function):
             dwp = torch.empty((k, k, cinp, coutp), device=x.device, dtype=torch.float32)
             nb = L.ymx_conv_wgrad_workspace_bytes(b, h, w, cinp, coutp, k, stride)
             ws = torch.empty((max(nb, 16),), device=x.device, dtype=torch.uint8)
+            if trace is not None:
+                trace.append(L.ymx_conv_wgrad_kernel_label(b, h, w, cinp, coutp, k, stride).decode())
             # the weight gradient and the input gradient of a block are independent: the former
             # runs on a second stream while this one goes on with the latter
             side = _side_stream(x.device) if (overlap_wgrad and ctx.needs_input_grad[0]) else None
