@@ -6,20 +6,14 @@
 // pixels), same K order per accumulator -- results are bit-identical.  The K loop is
 // organised so that the matrix pipe of every SIMD always has a wave to serve:
 //
-//   groups    waves 0-3 and 4-7 (one of each per SIMD) run the same phase sequence one
-//             barrier apart: while one group issues its 16 MFMAs of a phase, the other
-//             does the LDS reads and the DMA issue of its next phase
-//   phases    four per 64-deep K tile, one quadrant (64 channels x 32 pixels) of the wave
-//             tile each:  (m0,n0) (m0,n1) (m1,n1) (m1,n0);  a phase is
-//                 LDS reads of the fragments that change | issue one 16 KB DMA piece |
-//                 counted vmcnt | barrier | 16 MFMAs | barrier
-//   pieces    a K tile is staged as four 16 KB pieces in the order they are first read:
-//             W(m0) X(n0) X(n1) W(m1) -- the rows of all waves' first/second channel
-//             halves and pixel halves.  Eight slots (two K tiles) of LDS; piece c is
-//             issued in phase c-6 and waited for in phase c-2 (four pieces may stay in
-//             flight), is read from phase c-1 on, and its slot is re-issued two or more
-//             phases after its last read -- every reader has then passed a barrier behind
-//             its reads, every writer's data is behind a wait and a barrier.
+//   groups    waves 0-3 and 4-7 (one of each per SIMD) run the same sequence one barrier
+//             apart: while one group issues the 32 MFMAs of two quadrants, the other does
+//             its LDS reads and DMA issue
+//   intervals four per 64-deep K tile (load 1 | mfma (m0,n0) (m0,n1) | load 2 | mfma (m1,n1)
+//             (m1,n0)), a barrier behind each
+//   pieces    a K tile is staged as four 16 KB pieces W(m0) X(n0) X(n1) W(m1) -- the rows of
+//             all waves' first/second channel halves and pixel halves.  Eight slots (two K
+//             tiles) of LDS; counted vmcnt waits, see the loop
 #include "conv_epilogue.h"
 
 namespace ymx {
@@ -147,7 +141,7 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     typedef std::integral_constant<int, 2> I2;
     typedef std::integral_constant<int, 3> I3;
 
-    // ---- prologue: pieces 0..5 in flight, pieces 0 and 1 landed --------------------------
+    // ---- prologue: pieces 0..5 in flight, pieces 0, 1 and 2 landed -----------------------
     issue(0, I0{});
     issue(0, I1{});
     issue(0, I2{});
@@ -155,7 +149,7 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     issue(1, I0{});
     issue(1, I1{});
     YMX_STAMP(1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     YMX_STAMP(2);
     if (group == 1) __builtin_amdgcn_s_barrier();          // second group runs one barrier behind
@@ -167,34 +161,38 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    // between the LDS reads / DMA issue of a phase and its MFMAs
-    auto gate = [&]() {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but the four youngest pieces are in
-        barrier();
-    };
+    // Four intervals per K tile: a wave alternates between a LOAD interval (fragment reads, DMA
+    // issue, waits) and an MFMA interval of two quadrants (32 MFMAs); the second group runs one
+    // barrier behind, so on every SIMD one wave computes while the other loads.
+    //   load 1:  A(m0), B(n0), B(n1) of tile kt; issue X(n1), W(m1) of tile kt+1
+    //   mfma 1:  (m0,n0) (m0,n1)
+    //   load 2:  A(m1) of tile kt; issue W(m0), X(n0) of tile kt+2
+    //   mfma 2:  (m1,n1) (m1,n0)
+    // Eight DMA instructions per wave and K tile in a fixed order.  vmcnt(8) at the end of load 1
+    // = "W(m1) of THIS tile has landed" (read in load 2: one more barrier for this group, and
+    // the other group's same wait lies before that barrier too); vmcnt(6) at the end of load 2 =
+    // "W(m0), X(n0), X(n1) of the next tile have landed" (read in its load 1).  A load interval
+    // ends with lgkmcnt(0), so its reads are complete before the barrier behind it and the slot
+    // of a piece may be re-issued from the next interval on; every re-issue here is later.
     for (int kt = 0; kt < nk; ++kt) {
-        // phase 0: quadrant (m0, n0); issue X(n1) of tile kt+1
         read_a(kt, 0);
         read_b(kt, 0);
-        issue(kt + 1, I2{});
-        gate();
-        mfma_quadrant(I0{}, I0{});
-        barrier();
-        // phase 1: quadrant (m0, n1); issue W(m1) of tile kt+1
         read_b(kt, 1);
+        issue(kt + 1, I2{});
         issue(kt + 1, I3{});
-        gate();
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        barrier();
+        mfma_quadrant(I0{}, I0{});
         mfma_quadrant(I0{}, I1{});
         barrier();
-        // phase 2: quadrant (m1, n1); issue W(m0) of tile kt+2
         read_a(kt, 1);
         issue(kt + 2, I0{});
-        gate();
-        mfma_quadrant(I1{}, I1{});
-        barrier();
-        // phase 3: quadrant (m1, n0), fragments already in registers; issue X(n0) of tile kt+2
         issue(kt + 2, I1{});
-        gate();
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        barrier();
+        mfma_quadrant(I1{}, I1{});
         mfma_quadrant(I1{}, I0{});
         barrier();
     }

@@ -90,11 +90,28 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
     }
     const unsigned whalf = (unsigned)(64 * a.Kw * 2);
 
-    auto issue_w = [&](int kt, int half) {
+    auto issue_w = [&](int kt, int half) {              // prologue form
         const unsigned sbase = ring0 + (unsigned)(((kt & 1) * 2 + half) * WPIECE + wave * 2048);
         const unsigned base = (unsigned)kt * 128u + (half ? whalf : 0u);
 #pragma unroll
         for (int i = 0; i < 2; ++i) lds_dma16(wrsrc, sbase + (unsigned)(i * 1024), kt < nk ? base + woff[i] : OOB);
+    };
+    // Loop form: wcur[half][i] is this lane's offset in K tile kt (advanced by 128 bytes per tile),
+    // the tile distance goes into the instruction's immediate offset.  Tiles past the end of K
+    // (the last two issues) fetch whatever lies behind the row -- or zeros past the buffer -- into
+    // ring slots that nothing reads any more.
+    unsigned wcur[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { wcur[0][i] = woff[i]; wcur[1][i] = woff[i] + whalf; }
+    auto issue_w_next = [&](int kt) {                   // W(m1) of tile kt + 1
+        const unsigned sbase = ring0 + (unsigned)((((kt + 1) & 1) * 2 + 1) * WPIECE + wave * 2048);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lds_dma16_steady<128>(wrsrc, sbase + (unsigned)(i * 1024), wcur[1][i]);
+    };
+    auto issue_w_next2 = [&](int kt) {                  // W(m0) of tile kt + 2
+        const unsigned sbase = ring0 + (unsigned)(((kt & 1) * 2) * WPIECE + wave * 2048);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lds_dma16_steady<256>(wrsrc, sbase + (unsigned)(i * 1024), wcur[0][i]);
     };
     // slab piece `idx` of channel block cb into slab cb&1; out-of-range idx / cb: a no-op
     // instruction (zeros into the spare KB) so that the instruction count stays constant
@@ -103,6 +120,12 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
         const unsigned dst = real ? lds0 + (unsigned)((cb & 1) * slab_bytes + idx * 1024) : dump;
         const unsigned src = real ? slab_off0 + (unsigned)idx * slab_step + (unsigned)cb * 128u : OOB;
         lds_dma16(xrsrc, dst, src);
+    };
+    auto issue_slab_steady = [&](int cb, int idx) {
+        const bool real = idx < npieces && cb < ncb;
+        const unsigned dst = real ? lds0 + (unsigned)((cb & 1) * slab_bytes + idx * 1024) : dump;
+        const unsigned src = real ? slab_off0 + (unsigned)idx * slab_step + (unsigned)cb * 128u : OOB;
+        lds_dma16_steady<0>(xrsrc, dst, src);
     };
 
     // ---- prologue: slab of block 0, weights of tile 0 and W(m0) of tile 1 --------------------
@@ -148,18 +171,21 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
     // pixel half nh of the current tap: slab rows hb + (2*nh + jb) * 16.  Where the tap falls
     // outside the image the lane reads the always-zero spare KB instead (one select on the
     // address; lanes sharing that address are a broadcast, not a bank conflict)
-    const int zero_off = 2 * slab_bytes + 4 * WPIECE;
+    typedef unsigned int frag_u32x4_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const frag_u32x4_t *lds_frag_t;
+    const unsigned zero_abs = lds0 + (unsigned)(2 * slab_bytes + 4 * WPIECE);
     auto read_b = [&](int slab_off, int shift, int tap, int nh, int set, bool live) {
         const int hb = hb0 + shift;
-        const int base = slab_off + hb * 128 + ((q4 ^ (hb & 7)) << 4);     // (hb + 16 j) & 7 == hb & 7
+        const unsigned base = (lds0 + (unsigned)slab_off) + (unsigned)(hb * 128 + ((q4 ^ (hb & 7)) << 4));     // (hb + 16 j) & 7 == hb & 7
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
             const int j = nh * 2 + jb;
             if (j >= NJ) continue;
-            const bool ok = live && ((fmask[j] >> tap) & 1u);
-            const int off = ok ? base + j * 2048 : zero_off;
-            bfr[set][jb][0] = *(const uint4 *)(smem + off);
-            bfr[set][jb][1] = *(const uint4 *)(smem + (off ^ 64));          // chunk 4 + q4
+            // all ones where the tap lies inside the image for this lane's pixel, else zero: picks the slab row or the zero row
+            const unsigned in = live ? (unsigned)__builtin_amdgcn_sbfe((int)fmask[j], (unsigned)tap, 1u) : 0u;
+            const unsigned off = ((base + (unsigned)(j * 2048)) & in) | (zero_abs & ~in);
+            bfr[set][jb][0] = __builtin_bit_cast(uint4, *(lds_frag_t)(uintptr_t)off);
+            bfr[set][jb][1] = __builtin_bit_cast(uint4, *(lds_frag_t)(uintptr_t)(off ^ 64u));          // chunk 4 + q4
         }
     };
     auto mfma_quadrant = [&](auto mh_tag, auto nh_tag, auto set_tag) {
@@ -200,43 +226,55 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
     YMX_STAMP(2);
     if (group == 1) barrier();                             // second group runs one barrier behind
 
-    // Per K tile each wave issues W(m1) of the next tile (phase 1), one slab-class instruction
-    // (phase 2) and W(m0) of the tile after next (phase 3): five instructions.  vmcnt(5)
-    // after the issue of phase 1 therefore means "W(m1) of this tile has landed" (read in
-    // phase 2), after the issue of phase 3 "W(m0) of the next tile has landed" (read in its
-    // phase 0); a slab instruction of K tile j is covered by the wait in phase 3 of tile j+1.
-    // Every slot is re-issued two or more phases after its last read.
-    // (Measured alternatives, both slower than this (12, 4, 8, 0) LDS reads per phase: reading
-    // the next tile's first pixel half in phase 3, (8, 4, 8, 4), by 8 %; cutting the phases by
-    // K half instead of pixel half, (8, 8, 4, 4), by 2-3 %.)
+    // Four intervals per K tile, separated by barriers: a wave alternates between a LOAD interval
+    // (fragment reads into registers its last MFMAs are done with, DMA issue, waits) and an
+    // MFMA interval of two quadrants (32 MFMAs); the second group runs one barrier behind, so
+    // on every SIMD one wave is in its MFMA interval while the other loads.
+    //   load 1:  A(m0), B(n0), B(n1) of this tile (16 reads and the tap / border arithmetic)
+    //   mfma 1:  quadrants (m0,n0) (m0,n1)
+    //   load 2:  A(m1) (8 reads); issue W(m1) of the next tile, W(m0) of the tile after next and
+    //            one slab piece
+    //   mfma 2:  quadrants (m1,n1) (m1,n0)
+    // The loading wave gets only the issue slots the MFMA wave of its SIMD leaves free, so what it
+    // has to issue is what an interval costs beyond its 32 MFMAs; measured per K tile with all
+    // five DMA instructions in load 1: load 1 = 770 cycles, load 2 = 280, an MFMA interval 580
+    // -- hence every DMA instruction sits in load 2 (520 / 480 / 580: -4 .. -6 % per layer).
+    // Five DMA instructions per wave and K tile in a fixed order (W(m1) x 2, W(m0) x 2, slab), so
+    // the counted waits mean: vmcnt(3) at the end of load 1 = "W(m1) of THIS tile (issued in the
+    // last tile's load 2) has landed" -- read in load 2, after one more barrier for this group and
+    // after the other group's same wait; vmcnt(6) at the end of load 2 = "W(m0) of the next tile
+    // (issued one tile ago) has landed" -- read in its load 1.  A slab piece is covered by the
+    // vmcnt(3) one tile later.  Every load interval ends with lgkmcnt(0): a fragment read is
+    // complete before the barrier that follows it, so a ring slot or slab may be re-issued from
+    // the next interval on (the other group's reads of it ended one barrier earlier still).
     int cb = 0, tap = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const int slab = (cb & 1) * slab_bytes;
         const int tr = (tap * 11) >> 5;                     // tap / 3 for tap < 9
         const int shift = tr * a.W + (tap - tr * 3);
-        // phase 0: quadrant (m0, n0)
+        // load 1
         read_a(kt, 0);
         read_b(slab, shift, tap, 0, 0, true);
-        barrier();
-        mfma_quadrant(I0{}, I0{}, I0{});
-        barrier();
-        // phase 1: quadrant (m0, n1)
         read_b(slab, shift, tap, 1, 1, true);
-        issue_w(kt + 1, 1);
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         barrier();
+        // mfma 1
+        mfma_quadrant(I0{}, I0{}, I0{});
         mfma_quadrant(I0{}, I1{}, I1{});
         barrier();
-        // phase 2: quadrant (m1, n1); background fetch of the next block's slab
+        // load 2
         read_a(kt, 1);
-        issue_slab(tap < 6 ? cb + 1 : ncb, tap * 8 + wave);
+        issue_w_next(kt);
+        issue_w_next2(kt);
+        issue_slab_steady(tap < 6 ? cb + 1 : ncb, tap * 8 + wave);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { wcur[0][i] += 128u; wcur[1][i] += 128u; }
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         barrier();
+        // mfma 2
         mfma_quadrant(I1{}, I1{}, I1{});
-        barrier();
-        // phase 3: quadrant (m1, n0), fragments already in registers
-        issue_w(kt + 2, 0);
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        barrier();
         mfma_quadrant(I1{}, I0{}, I0{});
         barrier();
         if (++tap == 9) { tap = 0; ++cb; }

@@ -36,6 +36,25 @@ __device__ __forceinline__ void lds_dma16(const i32x4_t rsrc, unsigned lds_addr,
                  : "memory");
 }
 
+// The same inside a steady-state loop: IMM is added to the buffer offset by the instruction
+// itself (12-bit immediate) -- the hardware adds an instruction offset to the LDS address as
+// well, so M0 gets lds_addr - IMM -- and only the one wait state between the scalar write of M0 and
+// the LDS-DMA that reads it is inserted.  The five wait states of lds_dma16 cover a descriptor
+// or LDS address that a VECTOR instruction (v_readfirstlane) has just written; callers of this
+// form pass scalar-computed, long-lived operands.
+template <int IMM>
+__device__ __forceinline__ void lds_dma16_steady(const i32x4_t rsrc, unsigned lds_addr, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "buffer_load_dwordx4 %1, %3, 0 offen offset:%4 lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_addr - (unsigned)IMM), "s"(rsrc), "i"(IMM)
+                 : "memory");
+}
+
 }  // namespace ymx
 
 // ---- in-kernel time stamps (diagnostic build only: make stamps) -----------------------
