@@ -51,9 +51,8 @@ const char *ymx_last_error(void);
  * output tiles for which a bf16 convolution with more than 128 output channels runs on the
  * large-tile LDS-DMA kernel instead of the 128x128 kernel (default 160; 0 forces it, a huge
  * value disables it; ymx_op.min_tiles overrides it per op).  "dma_variant": which large-tile
- * kernel wide layers use (5, the default: chosen per shape -- input pixels resident in LDS
- * for 3x3 stride 1, phase-staggered wave groups for long 1x1 layers, the two-stage kernel
- * otherwise; 1: two-stage 256x256 everywhere; 2: 256x128 tile, two workgroups per CU; 4:
+ * kernel wide layers use (5, the default: input pixels resident in LDS for 3x3 stride 1,
+ * phase-staggered wave groups otherwise; 1: two-stage 256x256 everywhere; 2: 256x128 tile, two workgroups per CU; 4:
  * phase-staggered wave groups everywhere).  "dma_stages": pipeline depth (3 or 4, default
  * 4) of the 32- and 64-channel narrow-layer tiles.  "dma_narrow": bf16 layers of <= 128
  * output channels with at least dma_min_tiles 256-pixel tiles run on the LDS-DMA kernels

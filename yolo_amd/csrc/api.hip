@@ -37,8 +37,8 @@ int check_launch(const char *what) {
 // only its own later calls, so concurrent callers never see each other's settings and
 // nothing here needs a lock.  Every thread starts from the defaults.
 struct Tuning {
-    long long variant = 5;      // wide layers: 5 = resident-slab kernel for 3x3 stride 1, phase-staggered kernel for
-                                // long 1x1 layers, the two-stage 256x256 kernel otherwise; 1, 2, 4: see ymx_set_option
+    long long variant = 5;      // wide layers: 5 = resident-slab kernel for 3x3 stride 1, phase-staggered kernel
+                                // otherwise; 1, 2, 4: see ymx_set_option
     long long narrow = 2;       // layers of <= 128 output channels: 2 = LDS-DMA kernels (resident input slab for
                                 // 3x3 stride 1 with 32/64 input channels), 1 = without the slab kernel, 0 = register-staged
     long long min_tiles = -1;   // < 0: the default below
@@ -143,11 +143,11 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         if (dtype == YMX_BF16 && Cout > 128) {
             const long long tiles = ((long long)(a.P + 255) / 256) * ((Cout + 255) / 256);
             if (tiles >= min_tiles) {
-                // 3x3 stride 1: input pixels resident in LDS across the taps; long 1x1 layers
-                // (several rounds of tiles): phase-staggered wave groups; the two-stage kernel
-                // for the rest (measured per shape class on MI355X)
+                // 3x3 stride 1: input pixels resident in LDS across the taps; everything else:
+                // phase-staggered wave groups (2-5 % ahead of the two-stage kernel on every wide
+                // 1x1 and stride-2 layer of the detector since its loop has four intervals)
                 int which = (int)t_opt.variant;
-                if (which == 5) which = conv_halo_eligible(a) ? 5 : ((k == 1 && tiles >= 600) ? 4 : 1);
+                if (which == 5) which = conv_halo_eligible(a) ? 5 : 4;
                 static const char *const names[6] = {"", "dma", "dma2", "", "dma4", "halo"};
                 if (label) { *label = (which == 5 && conv_halo_tile_pixels(a) == 192) ? "halo192" : names[which]; return YMX_OK; }
                 switch (which) {

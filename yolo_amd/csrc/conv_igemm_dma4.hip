@@ -80,7 +80,18 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
             for (int i = 0; i < 2; ++i) lds_dma16(wrsrc, sbase + (unsigned)(i * 1024), kt < nk ? base + woff[i] : OOB);
         } else {
             if constexpr (POS == 1) {       // K index -> (tap, channel) -> (row, col), once per tile
-                k_decode(a, kt * 64 + chunk * 8, tapoff, tapbit);
+                if (a.CB == 64 && a.k <= 3) {
+                    // whole 64-channel blocks: a K tile is one (block, tap), the same for every lane,
+                    // so the decode is scalar arithmetic
+                    const int kk = a.k * a.k;
+                    const int blk = kk == 1 ? kt : (int)(((unsigned)kt * 7282u) >> 16);      // kt / 9 for kt < 32768
+                    const int tap = kt - blk * kk;
+                    const int tr = kk == 1 ? 0 : (tap * 11) >> 5, tc = tap - tr * a.k;       // tap / 3 for tap < 9
+                    tapoff = (tr * a.W + tc) * a.x_ld + blk * 64 + chunk * 8;
+                    tapbit = kt < nk ? (1u << tap) : 0u;
+                } else {
+                    k_decode(a, kt * 64 + chunk * 8, tapoff, tapbit);
+                }
             }
             constexpr int H = POS - 1;
 #pragma unroll
@@ -89,6 +100,24 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
                 lds_dma16(xrsrc, sbase + (unsigned)(i * 1024), off);
             }
         }
+    };
+
+    // Loop form of the weight pieces: wcur[1][i] / wcur[0][i] are this lane's offsets of W(m1) in
+    // K tile kt + 1 and of W(m0) in K tile kt + 2, advanced by 128 bytes per tile.
+    // Tiles past the end of K fetch whatever lies behind the row (or zeros past the buffer) into
+    // slots that nothing reads any more.
+    unsigned wcur[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { wcur[0][i] = woff[i] + 256u; wcur[1][i] = woff[i] + whalf + 128u; }
+    auto issue_w1_next = [&](int kt) {                  // W(m1) of tile kt + 1
+        const unsigned sbase = lds0 + (unsigned)((((kt + 1) & 1) * 4 + 3) * PIECE + wave * 2048);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lds_dma16_steady(wrsrc, sbase + (unsigned)(i * 1024), wcur[1][i]);
+    };
+    auto issue_w0_next2 = [&](int kt) {                 // W(m0) of tile kt + 2
+        const unsigned sbase = lds0 + (unsigned)(((kt & 1) * 4) * PIECE + wave * 2048);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lds_dma16_steady(wrsrc, sbase + (unsigned)(i * 1024), wcur[0][i]);
     };
 
     f32x4_t acc[NI][NJ];
@@ -174,28 +203,56 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     // "W(m0), X(n0), X(n1) of the next tile have landed" (read in its load 1).  A load interval
     // ends with lgkmcnt(0), so its reads are complete before the barrier behind it and the slot
     // of a piece may be re-issued from the next interval on; every re-issue here is later.
+    YMX_REGION_DECL;
     for (int kt = 0; kt < nk; ++kt) {
+        YMX_REGION_BEGIN(1);
         read_a(kt, 0);
         read_b(kt, 0);
         read_b(kt, 1);
+        YMX_REGION_END(1);
+        YMX_REGION_BEGIN(12);
         issue(kt + 1, I2{});
-        issue(kt + 1, I3{});
+        issue_w1_next(kt);
+        YMX_REGION_END(12);
+        YMX_REGION_BEGIN(2);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        YMX_REGION_END(2);
+        YMX_REGION_BEGIN(3);
         barrier();
+        YMX_REGION_END(3);
+        YMX_REGION_BEGIN(4);
         mfma_quadrant(I0{}, I0{});
         mfma_quadrant(I0{}, I1{});
+        YMX_REGION_END(4);
+        YMX_REGION_BEGIN(5);
         barrier();
+        YMX_REGION_END(5);
+        YMX_REGION_BEGIN(6);
         read_a(kt, 1);
-        issue(kt + 2, I0{});
+        YMX_REGION_END(6);
+        YMX_REGION_BEGIN(7);
+        issue_w0_next2(kt);
         issue(kt + 2, I1{});
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { wcur[0][i] += 128u; wcur[1][i] += 128u; }
+        YMX_REGION_END(7);
+        YMX_REGION_BEGIN(8);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        YMX_REGION_END(8);
+        YMX_REGION_BEGIN(9);
         barrier();
+        YMX_REGION_END(9);
+        YMX_REGION_BEGIN(10);
         mfma_quadrant(I1{}, I1{});
         mfma_quadrant(I1{}, I0{});
+        YMX_REGION_END(10);
+        YMX_REGION_BEGIN(11);
         barrier();
+        YMX_REGION_END(11);
     }
+    YMX_REGION_STORE(wave, lane);
     if (group == 0) barrier();
 
     // first half of the shortcut input (the fragment registers are free now)
@@ -242,3 +299,6 @@ int launch_conv_igemm_dma4(const ConvArgs &a, hipStream_t s) {
 }  // namespace ymx
 
 YMX_STAMP_EXPORT(ymx_debug_stamps_dma4)
+#ifdef YMX_REGION_DMA4
+YMX_REGION_EXPORT
+#endif

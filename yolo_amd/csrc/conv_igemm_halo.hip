@@ -96,22 +96,22 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
 #pragma unroll
         for (int i = 0; i < 2; ++i) lds_dma16(wrsrc, sbase + (unsigned)(i * 1024), kt < nk ? base + woff[i] : OOB);
     };
-    // Loop form: wcur[half][i] is this lane's offset in K tile kt (advanced by 128 bytes per tile),
-    // the tile distance goes into the instruction's immediate offset.  Tiles past the end of K
+    // Loop form: wcur[1][i] / wcur[0][i] are this lane's offsets of W(m1) in K tile kt + 1 and of
+    // W(m0) in K tile kt + 2, advanced by 128 bytes per tile.  Tiles past the end of K
     // (the last two issues) fetch whatever lies behind the row -- or zeros past the buffer -- into
     // ring slots that nothing reads any more.
     unsigned wcur[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { wcur[0][i] = woff[i]; wcur[1][i] = woff[i] + whalf; }
+    for (int i = 0; i < 2; ++i) { wcur[0][i] = woff[i] + 256u; wcur[1][i] = woff[i] + whalf + 128u; }
     auto issue_w_next = [&](int kt) {                   // W(m1) of tile kt + 1
         const unsigned sbase = ring0 + (unsigned)((((kt + 1) & 1) * 2 + 1) * WPIECE + wave * 2048);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) lds_dma16_steady<128>(wrsrc, sbase + (unsigned)(i * 1024), wcur[1][i]);
+        for (int i = 0; i < 2; ++i) lds_dma16_steady(wrsrc, sbase + (unsigned)(i * 1024), wcur[1][i]);
     };
     auto issue_w_next2 = [&](int kt) {                  // W(m0) of tile kt + 2
         const unsigned sbase = ring0 + (unsigned)(((kt & 1) * 2) * WPIECE + wave * 2048);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) lds_dma16_steady<256>(wrsrc, sbase + (unsigned)(i * 1024), wcur[0][i]);
+        for (int i = 0; i < 2; ++i) lds_dma16_steady(wrsrc, sbase + (unsigned)(i * 1024), wcur[0][i]);
     };
     // slab piece `idx` of channel block cb into slab cb&1; out-of-range idx / cb: a no-op
     // instruction (zeros into the spare KB) so that the instruction count stays constant
@@ -125,7 +125,7 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
         const bool real = idx < npieces && cb < ncb;
         const unsigned dst = real ? lds0 + (unsigned)((cb & 1) * slab_bytes + idx * 1024) : dump;
         const unsigned src = real ? slab_off0 + (unsigned)idx * slab_step + (unsigned)cb * 128u : OOB;
-        lds_dma16_steady<0>(xrsrc, dst, src);
+        lds_dma16_steady(xrsrc, dst, src);
     };
 
     // ---- prologue: slab of block 0, weights of tile 0 and W(m0) of tile 1 --------------------
@@ -248,37 +248,61 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
     // complete before the barrier that follows it, so a ring slot or slab may be re-issued from
     // the next interval on (the other group's reads of it ended one barrier earlier still).
     int cb = 0, tap = 0;
+    YMX_REGION_DECL;
     for (int kt = 0; kt < nk; ++kt) {
         const int slab = (cb & 1) * slab_bytes;
         const int tr = (tap * 11) >> 5;                     // tap / 3 for tap < 9
         const int shift = tr * a.W + (tap - tr * 3);
         // load 1
+        YMX_REGION_BEGIN(1);
         read_a(kt, 0);
         read_b(slab, shift, tap, 0, 0, true);
         read_b(slab, shift, tap, 1, 1, true);
+        YMX_REGION_END(1);
+        YMX_REGION_BEGIN(2);
         asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        YMX_REGION_END(2);
+        YMX_REGION_BEGIN(3);
         barrier();
+        YMX_REGION_END(3);
         // mfma 1
+        YMX_REGION_BEGIN(4);
         mfma_quadrant(I0{}, I0{}, I0{});
         mfma_quadrant(I0{}, I1{}, I1{});
+        YMX_REGION_END(4);
+        YMX_REGION_BEGIN(5);
         barrier();
+        YMX_REGION_END(5);
         // load 2
+        YMX_REGION_BEGIN(6);
         read_a(kt, 1);
+        YMX_REGION_END(6);
+        YMX_REGION_BEGIN(7);
         issue_w_next(kt);
         issue_w_next2(kt);
         issue_slab_steady(tap < 6 ? cb + 1 : ncb, tap * 8 + wave);
 #pragma unroll
         for (int i = 0; i < 2; ++i) { wcur[0][i] += 128u; wcur[1][i] += 128u; }
+        YMX_REGION_END(7);
+        YMX_REGION_BEGIN(8);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        YMX_REGION_END(8);
+        YMX_REGION_BEGIN(9);
         barrier();
+        YMX_REGION_END(9);
         // mfma 2
+        YMX_REGION_BEGIN(10);
         mfma_quadrant(I1{}, I1{}, I1{});
         mfma_quadrant(I1{}, I0{}, I0{});
+        YMX_REGION_END(10);
+        YMX_REGION_BEGIN(11);
         barrier();
+        YMX_REGION_END(11);
         if (++tap == 9) { tap = 0; ++cb; }
     }
+    YMX_REGION_STORE(wave, lane);
     if (group == 0) barrier();
 
     // first half of the shortcut input (the fragment registers are free now)
@@ -352,3 +376,6 @@ int launch_conv_igemm_halo(const ConvArgs &a, hipStream_t s) {
 }  // namespace ymx
 
 YMX_STAMP_EXPORT(ymx_debug_stamps_dma5)
+#ifdef YMX_REGION_HALO
+YMX_REGION_EXPORT
+#endif
