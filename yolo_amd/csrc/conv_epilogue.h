@@ -24,6 +24,17 @@
 namespace ymx {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int epi_u32x4_t;
+typedef __bf16 epi_bf16x2_t __attribute__((ext_vector_type(2)));
+
+// Two IEEE additions (no contraction with whatever produced the operands) and one packed
+// round-to-nearest-even conversion of a pair: v_pk_add_f32 and v_cvt_pk_bf16_f32.
+__device__ __forceinline__ f32x2_t epi_add2(f32x2_t a, f32x2_t b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ uint32_t epi_pack2(f32x2_t v) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, epi_bf16x2_t));
+}
 
 // HQMAX = channels transposed at a time: 64 (128-byte output runs, 16 KB image per wave) or 32
 // (64-byte runs, 8 KB per wave: for kernels that trade run length for workgroups per CU).
@@ -130,30 +141,29 @@ __device__ __forceinline__ void epi_run(const ConvArgs &a, f32x4_t (&acc)[NI][NJ
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] = nxt[r];
                 if (n + 1 < NPASS) read_row(px + PPI, nxt);     // next pass's row is in flight during this one's math
+                // pairs of neighbouring channels stay pairs from the affine step to the packed
+                // conversion, so that no instruction is spent on re-pairing them
+                f32x2_t o[4];
 #pragma unroll
-                for (int r = 0; r < 8; r += 2) {
-                    const f32x2_t o = affine_act2<ACT>(f32x2_t{v[r], v[r + 1]}, f32x2_t{sc[r], sc[r + 1]},
-                                                       f32x2_t{sh[r], sh[r + 1]});
-                    v[r] = o.x;
-                    v[r + 1] = o.y;
-                }
+                for (int r = 0; r < 4; ++r)
+                    o[r] = affine_act2<ACT>(f32x2_t{v[2 * r], v[2 * r + 1]}, f32x2_t{sc[2 * r], sc[2 * r + 1]},
+                                            f32x2_t{sh[2 * r], sh[2 * r + 1]});
                 if constexpr (RES) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         // a separately rounded add (never fused into the activation's last
                         // multiply): every conv kernel must give the same bits
-                        v[2 * r] = __fadd_rn(v[2 * r], __uint_as_float(rpre[half][n][r] << 16));
-                        v[2 * r + 1] = __fadd_rn(v[2 * r + 1], __uint_as_float(rpre[half][n][r] & 0xffff0000u));
+                        const unsigned w = rpre[half][n][r];
+                        o[r] = epi_add2(o[r], f32x2_t{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)});
                     }
                 }
                 if (p < a.P && co < a.Cout) {
                     OT *yp = y + (size_t)p * a.y_ld + co;
                     if constexpr (sizeof(OT) == 2) {
-                        store_stream16(yp, pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]),
-                                       pack2_bf16(v[6], v[7]));
+                        store_stream16(yp, epi_pack2(o[0]), epi_pack2(o[1]), epi_pack2(o[2]), epi_pack2(o[3]));
                     } else {
-                        store_stream16(yp, v[0], v[1], v[2], v[3]);
-                        store_stream16(yp + 4, v[4], v[5], v[6], v[7]);
+                        store_stream16(yp, o[0].x, o[0].y, o[1].x, o[1].y);
+                        store_stream16(yp + 4, o[2].x, o[2].y, o[3].x, o[3].y);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
