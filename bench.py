@@ -21,7 +21,12 @@ Besides the headline value the line carries
                 dense bf16 MFMA peak; `traffic` = HBM bytes per launch of that kernel from
                 the committed rocprofv3 --pmc passes (profiles/), null if there are none;
   cpu_baseline  the CPU oracle (torch-CPU fp32 convs + C post-processing) timed on this
-                host on a bounded sample of the same workload (rank 0, N = 1 only).
+                host on a bounded sample of the same workload (rank 0, N = 1 only);
+  breakdown.stress / breakdown.train   (single GPU, default shape) short legs of the NMS-stress
+                and training-step workloads -- `--workload nms-stress` / `--workload train` run
+                alone -- each with value, ms_per_step, roofline and its own cpu_baseline.
+The K timed steps are repeated (`repeats`) so that the timed region lasts about two seconds;
+value and ms_per_step are per step over all of them.
 """
 import argparse
 import json
@@ -137,7 +142,8 @@ def postproc_bytes(B, N, C, m_mean, head_bytes, total=32):
 
 def stress_workload(args, dev):
     """BASELINE config 4: decode + filter + combined NMS alone on synthetic head maps of a
-    1280x1280 input (100 800 candidates per image, 80 classes, score threshold 0.001)."""
+    1280x1280 input (100 800 candidates per image, 80 classes, score threshold 0.001).
+    Returns the result line (a dict)."""
     from yolo_amd import _lib
     from yolo_amd import utils as U
     import yolo_amd as Y
@@ -212,7 +218,7 @@ def stress_workload(args, dev):
     }
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_stress(C)
-    print(json.dumps(line), flush=True)
+    return line
 
 
 def cpu_baseline_stress(C, budget_s=15.0):
@@ -398,7 +404,7 @@ def train_workload(args, dev, rank, world):
         dt = float(tt.item())
     last = float(loss.detach())
     if rank != 0:
-        return
+        return None
     ms = dt / args.steps * 1e3
     total_flops = 3.0 * flops[0]                     # forward, input gradient, weight gradient
     result = {
@@ -420,7 +426,7 @@ def train_workload(args, dev, rank, world):
     }
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_train(C, S)
-    print(json.dumps(result), flush=True)
+    return result
 
 
 def cpu_baseline_train(C, side, budget_s=25.0):
@@ -479,6 +485,10 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the short nms-stress and train legs that the default single-GPU run appends under breakdown")
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="the K timed steps are repeated until the timed region lasts about this long (0: exactly K steps)")
     ap.add_argument("--per-op", action="store_true", help="also print the per-launch table to stderr")
     ap.add_argument("--workload", default="detector", choices=["detector", "nms-stress", "train"],
                     help="detector (default): the whole hot path; nms-stress: decode+filter+NMS alone on 100 800 "
@@ -513,12 +523,14 @@ def main():
             raise SystemExit("the nms-stress workload is a single-GPU measurement")
         if args.batch == 64:
             args.batch = 32                          # the configuration's batch unless overridden
-        stress_workload(args, dev)
+        print(json.dumps(stress_workload(args, dev)), flush=True)
         return
     if args.workload == "train":
         if args.steps == 20:
             args.steps = 10
-        train_workload(args, dev, rank, world)
+        result = train_workload(args, dev, rank, world)
+        if rank == 0:
+            print(json.dumps(result), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -544,11 +556,25 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    # The timed region is `repeats` back-to-back passes of the K steps, sized from one untimed
+    # step so that it lasts about two seconds (K steps alone are ~0.2 s: too short for a
+    # sampling power / activity monitor to see); every figure below is per step.
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    est = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([est], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        est = float(t.item())
+    repeats = 1 if args.min_seconds <= 0 else max(1, min(200, int(-(-args.min_seconds // max(est * args.steps, 1e-6)))))
+    timed_steps = args.steps * repeats
+    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(timed_steps):
         out = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -559,15 +585,16 @@ def main():
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    value = global_batch * args.steps / elapsed
+    ms_per_step = elapsed / timed_steps * 1e3
+    value = global_batch * timed_steps / elapsed
     valid_mean = float(out[3].float().mean().item())
 
     line = {
         "metric": "images/sec (fwd+decode+NMS) at %d^2" % S,
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic", "repeats": repeats, "timed_steps": timed_steps,
+        "timed_seconds": round(elapsed, 3),
         "config": {"workload": "Darknet53+YoloV3(C=%d) forward + decode + filter + combined NMS, %dx%d, batch %d per GPU, "
                                "%s storage / fp32 accumulate, random weights (activation-calibrated)" % (C, S, S, B, args.dtype),
                    "global_batch": global_batch, "per_gpu_batch": B, "image_size": S, "num_classes": C,
@@ -622,6 +649,19 @@ def main():
                                  (i, nm, shp[0], shp[1], shp[2], shp[3], shp[4], ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(C, S)
+    if rank == 0 and world == 1 and not args.no_extra_legs and S == 416 and B == 64:
+        # BASELINE configs 4 and 5 on the same line, each a short leg of its own workload with its
+        # own roofline and CPU baseline
+        sub = argparse.Namespace(**vars(args))
+        sub.batch, sub.steps, sub.warmup = 32, 20, 3
+        leg = stress_workload(sub, dev)
+        line.setdefault("breakdown", {})["stress"] = {k: leg[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype",
+                                                                           "candidates_per_s", "config", "roofline", "roofline_nms",
+                                                                           "cpu_baseline") if k in leg}
+        sub.batch, sub.steps, sub.warmup = 64, 6, 2
+        leg = train_workload(sub, dev, 0, 1)
+        line["breakdown"]["train"] = {k: leg[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config",
+                                                           "roofline", "cpu_baseline") if k in leg}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -15,7 +15,7 @@ import os, sys
 sys.path.insert(0, %r)
 from yolo_amd import _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), %r)
-sys.argv = ['bench.py', '--steps', '20', '--warmup', '3', '--no-cpu-baseline', '--no-profile']
+sys.argv = ['bench.py', '--steps', '20', '--warmup', '3', '--no-cpu-baseline', '--no-profile', '--no-extra-legs']
 import runpy
 runpy.run_path(os.path.join(%r, 'bench.py'), run_name='__main__')
 """
