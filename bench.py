@@ -329,8 +329,8 @@ def cpu_baseline(num_classes, side, budget_s=15.0):
 def train_workload(args, dev, rank, world):
     """BASELINE config 5: one training step per timed step -- forward with the graph recorded,
     the YOLO loss at the three scales, back-propagation through every block (input, weight and
-    bias gradients), gradient averaging over the ranks (one bucketed all-reduce, N > 1 only),
-    plain SGD.  Batch = images per GPU (512 / 8 = 64 in the configuration)."""
+    bias gradients), gradient averaging over the ranks (bucketed all-reduces that start
+    during the backward pass, N > 1 only), the L2 kernel regulariser's gradient, plain SGD.  Batch = images per GPU (512 / 8 = 64 in the configuration)."""
     import numpy as np
     import torch.distributed as dist
     import yolo_amd as Y
@@ -358,6 +358,7 @@ def train_workload(args, dev, rank, world):
     fns = L.get_yolo_loss_at_scales([0, 1, 2], C, cfg["strides"], 0.5, cfg["xyscale"], cfg["anchors"])   # scales 2, 1, 0
     params = list(det.backbone.parameters()) + list(det.head.parameters())
     buckets = ydist.GradientBuckets(params) if world > 1 else None
+    reg = T.L2Regulariser(det)
     lr = 1e-7
     flops = [0.0]
 
@@ -372,10 +373,11 @@ def train_workload(args, dev, rank, world):
             for p in params:
                 p.grad = None
         else:
-            buckets.zero_()
-        loss.backward()
+            buckets.begin()
+        loss.backward()                  # with buckets: each bucket's all-reduce starts as its last gradient lands
         if buckets is not None:
-            buckets.reduce().wait()
+            buckets.wait()
+        reg.add_gradients_()             # kernel_regularizer l2(0.0005) of every convolution (layers.py:61)
         with torch.no_grad():
             torch._foreach_add_(params, [p.grad for p in params], alpha=-lr)
         return loss
@@ -413,9 +415,9 @@ def train_workload(args, dev, rank, world):
         "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "training step: Darknet53+YoloV3(C=%d) forward with saved pre-activations, YOLO loss at three scales, "
-                               "backward (dgrad on the forward kernels, MFMA wgrad, bias grad), %sSGD; %dx%d, batch %d per GPU, bf16 "
+                               "backward (dgrad on the forward kernels, MFMA wgrad, bias grad), %sL2 kernel regulariser, SGD; %dx%d, batch %d per GPU, bf16 "
                                "storage / fp32 accumulate and fp32 master weights, activation-calibrated random weights"
-                               % (C, "bucketed gradient all-reduce, " if world > 1 else "", S, S, B),
+                               % (C, "bucketed gradient all-reduce overlapped with the backward pass, " if world > 1 else "", S, S, B),
                    "global_batch": B * world, "per_gpu_batch": B, "image_size": S, "num_classes": C,
                    "parallelism": "dp%d" % world if world > 1 else "single GPU", "loss_first": round(first, 3), "loss_last": round(last, 3),
                    "peak_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)},

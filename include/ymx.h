@@ -301,8 +301,9 @@ int ymx_yolo_loss_grad(const float *conv, int conv_ld, const float *label, long 
 /* ---- backward pass of the convolution block ------------------------------------
  * The reference trains through TensorFlow's automatic differentiation of YOLOConv /
  * ResidialBlock / Upsample (layers.py:33-106); these are the pieces of that derivative.
- * A training forward keeps the pre-activation z = conv(x) + bias (ymx_conv2d_fused with
- * act = 0) and forms y = act(z) + residual with ymx_act_apply.  Given dy:
+ * A training forward keeps the pre-activation z = conv(x) + bias next to the output
+ * y = act(z) + residual: ymx_conv2d_fused_z writes both from one launch (layers without an
+ * activation: ymx_conv2d_fused with act = 0, z = y).  Given dy:
  *   dz = dy * act'(z)                      ymx_act_backward   (act 0: dz = dy, no call needed)
  *   dbias[c] = sum_p dz[p][c]              ymx_bias_grad      (two ordered stages, deterministic)
  *   dkernel[r][s][ci][co] = sum_p x[p+(r,s)][ci] * dz[p][co]
@@ -344,6 +345,20 @@ int ymx_upsample2x_backward(const void *dy, void *dx, int B, int H, int W, int C
  * dtype) bytes and feeds ymx_conv2d_fused(_ex) with Cin = dz_channels, Cout = Cin. */
 int ymx_pack_weights_dgrad(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dz_channels,
                            int dtype, void *stream);
+/* ymx_pack_weights (into w_fwd) and ymx_pack_weights_dgrad (into w_dgrad) of one kernel in one
+ * launch: what a training step does for every layer after each update of the weights.  Cin and
+ * dz_channels must take the MFMA kernels (multiples of 8 for bf16, of 4 for fp32). */
+int ymx_pack_weights_pair(const float *w_hwio, void *w_fwd, void *w_dgrad, int k, int Cin, int Cout,
+                          int dz_channels, int dtype, void *stream);
+/* Training forward of a convolution block (/root/reference/layers.py:41-90 with the value in
+ * front of the activation kept for the derivative): z = conv(x) * scale + shift rounded to bf16
+ * [B,H',W',Cout], y = act(conv(x) * scale + shift) + residual (bf16, the same bits as
+ * ymx_conv2d_fused gives), both dense.  bf16 compute; act 1 or 2; x_dtype as in
+ * ymx_conv2d_fused_ex.  The LDS-DMA kernels store both from their epilogue; shapes that take
+ * another kernel run as two launches (convolution into z, then ymx_act_apply). */
+int ymx_conv2d_fused_z(const void *x, const void *w, const void *scale, const void *shift, const void *residual,
+                       void *y, void *z, int B, int H, int W, int Cin, int Cout, int k, int stride, int act,
+                       int x_dtype, void *stream);
 
 /* ---- letterbox resize ---------------------------------------------------------
  * Replaces the image half of image_preprocess (utils.py:16-26): the image is resized by

@@ -83,6 +83,16 @@ def yolo_loss(pred, conv, label, bboxes, input_size, iou_loss_threshold):   # lo
     return red(giou_loss), red(conf_loss), red(prob_loss)
 
 
+def l2_penalty(kernels, coefficient=0.0005):
+    """What Keras adds to the loss it minimises for the reference's convolutions:
+    kernel_regularizer=tf.keras.regularizers.l2(0.0005) on every Conv2D kernel, biases left out
+    (/root/reference/layers.py:59-63); l2(c) is c * sum(w ** 2)."""
+    total = torch.zeros((), dtype=F64)
+    for k in kernels:
+        total = total + coefficient * k.to(F64).square().sum()
+    return total
+
+
 def loss_and_grad(target, output, scale, num_classes, strides, iou_loss_threshold, xyscale, anchors, weights=(1.0, 1.0, 1.0)):
     """((giou, conf, prob) as floats, d(w0*giou + w1*conf + w2*prob)/d output as a float64
     array shaped like ``output`` [B,S,S,3*(5+C)])."""

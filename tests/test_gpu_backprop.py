@@ -293,9 +293,9 @@ def test_small_network_gradients_and_descent():
 
 
 def test_detector_training_step_vs_oracle():
-    """Darknet53 + YoloV3 + the YOLO loss at the three scales, 64 x 64 inputs: the gradient of
-    every one of the 146 parameter tensors after back-propagation through 75 bf16 blocks
-    against the oracle (same bf16 storage roundings in the forward pass, fp32 autograd
+    """Darknet53 + YoloV3 + the YOLO loss at the three scales plus the L2 kernel regulariser of
+    every convolution, 64 x 64 inputs: the gradient of every one of the 146 parameter tensors
+    after back-propagation through 75 bf16 blocks against the oracle (same bf16 storage roundings in the forward pass, fp32 autograd
     backward).  Per tensor: cosine similarity and error relative to the tensor's scale.
     Measured: cosine >= 0.9997 on every tensor, scaled error median 1.3e-2, worst 3.6e-2 (what
     75 chained bf16 blocks leave; the single-block bound of 1e-2 is in test_conv_block_gradients)."""
@@ -336,7 +336,9 @@ def test_detector_training_step_vs_oracle():
         g, c, p = LT.yolo_loss(pred, conv5, tgt[:, :split].reshape(B, Si, Si, 3, D), tgt[:, split:].reshape(B, 128, 4),
                                Si * P.STRIDES[i], 0.5)
         total = total + g + c + p
-    total.backward()
+    kernels_o = [p["kernel"] for plist in (rbp, rhp) for p in plist]
+    penalty = LT.l2_penalty(kernels_o)                     # kernel_regularizer of every convolution (layers.py:61)
+    (total + penalty).backward()
     # GPU
     det = Detector(num_classes=C, dtype=torch.bfloat16)
     det.load_reference_params(bp, hp)
@@ -346,7 +348,10 @@ def test_detector_training_step_vs_oracle():
         s, m, l = det.head(*det.backbone(x.to(DEV)))
     loss = fns[2](targets[0], s) + fns[1](targets[1], m) + fns[0](targets[2], l)
     loss.backward()
+    reg = T.L2Regulariser(det)
+    reg.add_gradients_()
     assert abs(float(loss.detach()) - float(total.detach())) < 3e-2 * abs(float(total.detach()))
+    assert abs(float(reg.penalty()) - float(penalty.detach())) < 1e-3 * float(penalty.detach())    # fp32 master weights here, their bf16 roundings there
     convs = det.backbone.conv_layers() + det.head.conv_layers()
     got = []
     for conv in convs:
@@ -361,3 +366,130 @@ def test_detector_training_step_vs_oracle():
           (min(cos), float(np.median(cos)), max(err), float(np.median(err))))
     assert min(cos) > 0.999
     assert float(np.median(err)) < 2e-2 and max(err) < 6e-2
+
+
+Z_CASES = [   # B, H, W, Cin, Cout, k, stride, act, shortcut  -> the kernel family the shape is routed to
+    (8, 52, 52, 512, 1024, 3, 1, 2, False),      # resident-slab kernel, 256-pixel tiles
+    (8, 52, 52, 128, 256, 3, 1, 2, True),        # the same with the shortcut
+    (16, 13, 13, 512, 1024, 3, 1, 1, False),     # 192-pixel tiles
+    (8, 52, 52, 1024, 512, 1, 1, 2, False),      # phase-staggered kernel
+    (8, 52, 52, 256, 512, 3, 2, 1, False),       # stride 2
+    (4, 208, 208, 64, 32, 1, 1, 2, False),       # narrow LDS-DMA kernel
+    (4, 208, 208, 32, 64, 3, 1, 2, True),        # narrow input-slab kernel, shortcut
+    (4, 104, 104, 128, 64, 1, 1, 1, False),
+    (1, 13, 13, 256, 512, 3, 1, 2, True),        # too few tiles: register-staged kernel, two launches
+    (2, 20, 24, 40, 72, 3, 1, 2, False),         # channel counts off the tile sizes
+    (2, 64, 64, 3, 32, 3, 1, 2, False),          # first layer (fp32 images, direct kernel): two launches
+]
+
+
+@pytest.mark.parametrize("case", range(len(Z_CASES)))
+def test_training_forward_two_outputs(case):
+    """ymx_conv2d_fused_z through the C ABI: y carries the bits of the inference convolution
+    (ymx_conv2d_fused_ex with the activation and the shortcut), z those of the same
+    convolution without activation, for every kernel family and for the shapes that run as
+    two launches."""
+    from yolo_amd import _lib
+    B, H, W, cin, cout, k, stride, act, use_sc = Z_CASES[case]
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(900 + case)
+    first = cin % 8 != 0
+    x = torch.randn(B, H, W, cin, generator=g).to(DEV)
+    if not first:
+        x = x.bfloat16()
+    wt = (torch.randn(k, k, cin, cout, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(DEV)
+    shift = (0.1 * torch.randn(cout, generator=g)).to(DEV)
+    code = _lib.BF16
+    wp = torch.empty(L.ymx_packed_weight_bytes(k, cin, cout, code), dtype=torch.uint8, device=DEV)
+    _lib.launch("ymx_pack_weights", wp, _lib.ptr(wt), _lib.ptr(wp), k, cin, cout, code)
+    oh, ow = (H, W) if stride == 1 else ((H + 1 - k) // 2 + 1, (W + 1 - k) // 2 + 1)
+    sc = torch.randn(B, oh, ow, cout, generator=g).to(DEV).bfloat16() if use_sc else None
+    xd = _lib.dtype_code(x.dtype)
+
+    def conv(a, res):
+        y = torch.empty(B, oh, ow, cout, device=DEV, dtype=torch.bfloat16)
+        _lib.launch("ymx_conv2d_fused_ex", x, _lib.ptr(x), _lib.ptr(wp), None, _lib.ptr(shift), _lib.ptr(res), _lib.ptr(y), B, H, W, cin, cout,
+                    k, stride, a, code, xd, code, 0, 0, 0)
+        return y
+
+    want_y, want_z = conv(act, sc), conv(_lib.ACT_NONE, None)
+    y = torch.full((B, oh, ow, cout), float("nan"), device=DEV, dtype=torch.bfloat16)
+    z = torch.full_like(y, float("nan"))
+    _lib.launch("ymx_conv2d_fused_z", x, _lib.ptr(x), _lib.ptr(wp), None, _lib.ptr(shift), _lib.ptr(sc), _lib.ptr(y), _lib.ptr(z),
+                B, H, W, cin, cout, k, stride, act, xd)
+    torch.cuda.synchronize()
+    assert torch.equal(z.view(torch.int16), want_z.view(torch.int16))
+    if first or (B, H) == (1, 13):
+        # two launches: y = act(z rounded to bf16) + shortcut, one rounding more than the fused epilogue
+        ref = want_y.float()
+        assert float((y.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    else:
+        assert torch.equal(y.view(torch.int16), want_y.view(torch.int16))
+
+
+def test_weight_packs_of_a_training_step_in_one_launch():
+    """ymx_pack_weights_pair = ymx_pack_weights + ymx_pack_weights_dgrad, byte for byte."""
+    from yolo_amd import _lib
+    L = _lib.lib()
+    code = _lib.BF16
+    for k, cin, cout in ((3, 64, 128), (1, 256, 255), (3, 40, 72), (1, 1024, 512), (3, 8, 16)):
+        wt = torch.randn(k, k, cin, cout, generator=torch.Generator().manual_seed(k + cin)).to(DEV)
+        coutp = -(-cout // 8) * 8
+        nf, nb = L.ymx_packed_weight_bytes(k, cin, cout, code), L.ymx_packed_weight_bytes(k, coutp, cin, code)
+        f0, b0, f1, b1 = (torch.full((n,), 0x5a, dtype=torch.uint8, device=DEV) for n in (nf, nb, nf, nb))
+        _lib.launch("ymx_pack_weights", f0, _lib.ptr(wt), _lib.ptr(f0), k, cin, cout, code)
+        _lib.launch("ymx_pack_weights_dgrad", b0, _lib.ptr(wt), _lib.ptr(b0), k, cin, cout, coutp, code)
+        _lib.launch("ymx_pack_weights_pair", f1, _lib.ptr(wt), _lib.ptr(f1), _lib.ptr(b1), k, cin, cout, coutp, code)
+        assert torch.equal(f0, f1) and torch.equal(b0, b1), (k, cin, cout)
+
+
+def test_gradient_buckets_receive_the_block_gradients_in_place():
+    """With yolo_amd.dist.GradientBuckets the convolution blocks write weight and bias gradients
+    straight into the buckets (padded layers through one strided copy) and report them ready:
+    the same numbers as the gradients autograd would have been handed, every bucket started
+    during backward() in bucket order, and the L2 regulariser adds 2 * 0.0005 * kernel."""
+    from yolo_amd import dist as D, training as T
+    from yolo_amd.layers import YOLOConv, ResidialBlock
+    torch.manual_seed(5)
+    specs = [YOLOConv((3, 3, 32), downsample=True, dtype=torch.bfloat16, in_channels=3),
+             ResidialBlock(16, 32, dtype=torch.bfloat16),
+             YOLOConv((1, 1, 255), activation=None, dtype=torch.bfloat16, in_channels=32)]
+    x = torch.rand(2, 24, 24, 3).to(DEV)
+    block = specs[1]
+    block.layer_stack[0].build(32)
+    block.layer_stack[1].build(16)
+    net = torch.nn.ModuleList(specs).to(DEV)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(torch.randn_like(p) * (0.2 if p.dim() == 4 else 0.05))
+    params = list(net.parameters())
+
+    def run():
+        with T.backprop():
+            out = specs[2](block(specs[0](x)))
+        out.float().square().mean().backward()
+
+    run()
+    want = [p.grad.clone() for p in params]
+    gb = D.GradientBuckets(params, bucket_bytes=16 << 10)
+    assert len(gb.buckets) >= 3
+    for step in range(2):
+        gb.begin()
+        run()
+        torch.cuda.synchronize()
+        assert gb.launch_order == list(range(len(gb.buckets)))
+        gb.wait()
+        for p, w in zip(params, want):
+            assert p.grad.data_ptr() == p._grad_bucket[1].data_ptr()
+            assert torch.equal(p.grad, w), tuple(p.shape)
+    reg = T.L2Regulariser(net)
+    assert len(reg.kernels) == 4
+    reg.add_gradients_()
+    for m in net.modules():
+        if isinstance(m, YOLOConv):
+            i = [id(p) for p in params].index(id(m.kernel))
+            assert torch.allclose(m.kernel.grad, want[i] + 0.001 * m.kernel.detach(), rtol=1e-6, atol=1e-9)
+            j = [id(p) for p in params].index(id(m.bias))
+            assert torch.equal(m.bias.grad, want[j])
+    pen = float(reg.penalty())
+    assert abs(pen - 0.0005 * sum(float(k.detach().double().square().sum()) for k in reg.kernels)) < 1e-6 * pen

@@ -498,3 +498,15 @@ def test_labels_oracle_skips_boxes_without_a_cell():
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g, w)
     assert sum(float(np.abs(w).sum()) for w in want) > 0
+
+
+def test_l2_penalty_of_the_kernels():
+    """Keras l2(c): c * sum(w^2) per kernel (layers.py:61), so each kernel's gradient gains 2 c w."""
+    import torch
+    from oracle import loss_torch as LT
+    ks = [torch.randn(3, 3, 4, 5, generator=torch.Generator().manual_seed(i)).requires_grad_(True) for i in range(3)]
+    pen = LT.l2_penalty(ks)
+    assert abs(float(pen) - 0.0005 * sum(float((k.double() ** 2).sum()) for k in ks)) < 1e-12
+    pen.backward()
+    for k in ks:
+        assert torch.allclose(k.grad, 0.001 * k.detach(), rtol=1e-6, atol=0)

@@ -80,8 +80,10 @@ int reserve_lds(LdsReserve &st, const void *kern, int bytes, const char *what) {
 static int conv_impl(const void *x, const void *w, const void *scale, const void *shift,
                      const void *residual, void *y, int B, int H, int W, int Cin, int Cout, int k,
                      int stride, int act, int dtype, int x_dtype, int out_dtype, int x_ld, int res_ld,
-                     int y_ld, hipStream_t s, int op_min_tiles = 0, const char **label = nullptr) {
+                     int y_ld, hipStream_t s, int op_min_tiles = 0, const char **label = nullptr, void *z = nullptr) {
     // label != nullptr: validate and select only; *label names the kernel family, nothing is launched
+    // z != nullptr: the value before the activation is stored too (bf16, dense); kernels without
+    // that second output run as two launches, convolution into z and then y = act(z) + residual
     if (!x || !w || !y) return fail(YMX_EARG, "conv2d: null x, w or y");
     if (op_min_tiles < 0) return fail(YMX_EARG, "conv2d: negative min_tiles");
     const long long min_tiles = op_min_tiles > 0 ? op_min_tiles : dma_min_tiles();
@@ -123,6 +125,20 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
     set_fastdiv((unsigned)k, a.k_m, a.k_s);
     a.act = act;
     a.dtype = dtype; a.x_dtype = x_dtype; a.out_dtype = out_dtype;
+    if (z) {
+        if (dtype != YMX_BF16 || out_dtype != YMX_BF16 || act == YMX_ACT_NONE || a.y_ld != Cout || !aligned16(z))
+            return fail(YMX_EARG, "conv2d: the second output needs bf16, an activation, dense y and a 16-byte aligned z");
+    }
+    // the second output inside the kernel: the 16-byte store path of the LDS-DMA epilogue
+    const bool z_fused = z && Cout % 8 == 0 && (!residual || a.res_ld % 8 == 0);
+    auto two_pass = [&](int (*launch)(const ConvArgs &, hipStream_t)) {
+        ConvArgs c = a;
+        c.y = z; c.res = nullptr; c.res_bytes = 0; c.act = YMX_ACT_NONE; c.y_ld = Cout;
+        const int rc = launch(c, s);
+        if (rc) return rc;
+        if (residual && a.res_ld != Cout) return fail(YMX_EUNSUPPORTED, "conv2d: second output with a strided residual");
+        return launch_act(z, residual, y, (size_t)P * Cout, act, YMX_BF16, 0, s);
+    };
     if (conv_uses_mfma(Cin, dtype)) {
         if (x_dtype != dtype) return fail(YMX_EUNSUPPORTED, "conv2d: MFMA path needs x_dtype == dtype");
         const int kch = dtype == YMX_BF16 ? 8 : 4;
@@ -150,12 +166,11 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
                 if (which == 5) which = conv_halo_eligible(a) ? 5 : 4;
                 static const char *const names[6] = {"", "dma", "dma2", "", "dma4", "halo"};
                 if (label) { *label = (which == 5 && conv_halo_tile_pixels(a) == 192) ? "halo192" : names[which]; return YMX_OK; }
-                switch (which) {
-                case 1: return launch_conv_igemm_dma(a, s);
-                case 2: return launch_conv_igemm_dma2(a, s);
-                case 4: return launch_conv_igemm_dma4(a, s);
-                default: return launch_conv_igemm_halo(a, s);
-                }
+                int (*const fn)(const ConvArgs &, hipStream_t) = which == 1 ? launch_conv_igemm_dma : which == 2 ? launch_conv_igemm_dma2 :
+                                                                  which == 4 ? launch_conv_igemm_dma4 : launch_conv_igemm_halo;
+                if (z && !(z_fused && (!residual || a.res_bytes))) return two_pass(fn);
+                a.z = z;
+                return fn(a, s);
             }
         }
         // Narrow layers (the first backbone stages): memory-bound; the several-workgroups-
@@ -163,10 +178,13 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         if (dtype == YMX_BF16 && Cout <= 128 && t_opt.narrow && (a.P + 255) / 256 >= min_tiles) {
             const bool slab = t_opt.narrow == 2 && conv_slab2_eligible(a);
             if (label) { *label = slab ? "slab2" : "dma2"; return YMX_OK; }
-            return slab ? launch_conv_igemm_slab2(a, s) : launch_conv_igemm_dma2(a, s);
+            int (*const fn)(const ConvArgs &, hipStream_t) = slab ? launch_conv_igemm_slab2 : launch_conv_igemm_dma2;
+            if (z && !(z_fused && (!residual || a.res_bytes))) return two_pass(fn);
+            a.z = z;
+            return fn(a, s);
         }
         if (label) { *label = "igemm"; return YMX_OK; }
-        return launch_conv_igemm(a, s);
+        return z ? two_pass(launch_conv_igemm) : launch_conv_igemm(a, s);
     }
     if (!aligned16(y)) return fail(YMX_EARG, "conv2d: y must be 16-byte aligned");
     a.Kw = Cout;
@@ -177,7 +195,7 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
         a.x_bytes = (xb <= 0x80000000LL && aligned16(x)) ? (unsigned)xb : 0u;
     }
     if (label) { *label = conv_first_rows_eligible(a) ? "first_rows" : "direct"; return YMX_OK; }
-    return launch_conv_direct(a, s);
+    return z ? two_pass(launch_conv_direct) : launch_conv_direct(a, s);
 }
 
 }  // namespace ymx
@@ -246,6 +264,15 @@ int ymx_pack_weights_dgrad(const float *w_hwio, void *w_packed, int k, int Cin, 
     return launch_pack_weights(w_hwio, w_packed, k, dz_channels, Cin, dtype, (hipStream_t)stream, Cout);
 }
 
+int ymx_pack_weights_pair(const float *w_hwio, void *w_fwd, void *w_dgrad, int k, int Cin, int Cout, int dz_channels, int dtype,
+                          void *stream) {
+    if (!w_hwio || !w_fwd || !w_dgrad) return fail(YMX_EARG, "pack_weights_pair: null pointer");
+    if (k <= 0 || Cin <= 0 || Cout <= 0) return fail(YMX_EARG, "pack_weights_pair: non-positive size");
+    if (dz_channels < Cout) return fail(YMX_EARG, "pack_weights_pair: dz_channels %d below Cout %d", dz_channels, Cout);
+    if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "pack_weights_pair: dtype %d", dtype);
+    return launch_pack_weights_pair(w_hwio, w_fwd, w_dgrad, k, Cin, Cout, dz_channels, dtype, (hipStream_t)stream);
+}
+
 int ymx_conv2d_fused(const void *x, const void *w, const void *scale, const void *shift, const void *residual,
                      void *y, int B, int H, int W, int Cin, int Cout, int k, int stride, int act, int dtype,
                      void *stream) {
@@ -260,6 +287,14 @@ int ymx_conv2d_fused_ex(const void *x, const void *w, const void *scale, const v
         return fail(YMX_EARG, "conv2d: x_dtype %d / out_dtype %d", x_dtype, out_dtype);
     return conv_impl(x, w, scale, shift, residual, y, B, H, W, Cin, Cout, k, stride, act, dtype, x_dtype, out_dtype,
                      x_ld, res_ld, y_ld, (hipStream_t)stream);
+}
+
+int ymx_conv2d_fused_z(const void *x, const void *w, const void *scale, const void *shift, const void *residual, void *y,
+                       void *z, int B, int H, int W, int Cin, int Cout, int k, int stride, int act, int x_dtype, void *stream) {
+    if (!z) return fail(YMX_EARG, "conv2d_fused_z: null z");
+    if (x_dtype != YMX_F32 && x_dtype != YMX_BF16) return fail(YMX_EARG, "conv2d_fused_z: x_dtype %d", x_dtype);
+    return conv_impl(x, w, scale, shift, residual, y, B, H, W, Cin, Cout, k, stride, act, YMX_BF16, x_dtype, YMX_BF16, 0, 0, 0,
+                     (hipStream_t)stream, 0, nullptr, z);
 }
 
 int ymx_upsample2x_concat(const void *skip, const void *x, void *y, int B, int H, int W, int C1, int C2, int dtype,

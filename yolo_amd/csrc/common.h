@@ -107,11 +107,14 @@ template <int ACT> __device__ __forceinline__ float act_c(float v) {
     return v;
 }
 // act(v * sc + sh) for a pair (the affine step is one packed fma, as in affine_f).
-template <int ACT> __device__ __forceinline__ f32x2_t affine_act2(f32x2_t v, f32x2_t sc, f32x2_t sh) {
-    const f32x2_t x = __builtin_elementwise_fma(v, sc, sh);
+__device__ __forceinline__ f32x2_t affine2(f32x2_t v, f32x2_t sc, f32x2_t sh) { return __builtin_elementwise_fma(v, sc, sh); }
+template <int ACT> __device__ __forceinline__ f32x2_t act2(f32x2_t x) {
     if constexpr (ACT == YMX_ACT_MISH) return mish2_f(x);
     f32x2_t o = {act_c<ACT>(x.x), act_c<ACT>(x.y)};
     return o;
+}
+template <int ACT> __device__ __forceinline__ f32x2_t affine_act2(f32x2_t v, f32x2_t sc, f32x2_t sh) {
+    return act2<ACT>(affine2(v, sc, sh));
 }
 // 1 / (1 + e^-x) with the hardware exponential and reciprocal (1 ulp each): four instructions
 // instead of the dozen a correctly rounded division takes; the decode kernel spends most of
@@ -123,6 +126,8 @@ struct ConvArgs {
     const void *x, *w, *res;
     const float *scale, *shift;
     void *y;
+    void *z;                     // bf16 [P][Cout], dense, or null: second output, the value before the activation
+                                 // (what a training step keeps for the derivative); LDS-DMA kernels only
     int B, H, W, Cin, Cout, OH, OW;
     int k, stride, pad;
     int x_ld, res_ld, y_ld;      // pixel strides in elements
@@ -217,6 +222,8 @@ bool conv_first_rows_eligible(const ConvArgs &a);
 int launch_conv_direct(const ConvArgs &a, hipStream_t s);
 int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype,
                         hipStream_t s, int src_cout = 0);
+int launch_pack_weights_pair(const float *w_hwio, void *w_fwd, void *w_bwd, int k, int Cin, int Cout, int dz_channels, int dtype,
+                             hipStream_t s);
 int launch_upsample2x_concat(const void *skip, const void *x, void *y, int B, int H, int W, int C1,
                              int C2, int dtype, hipStream_t s);
 int launch_affine_act(const void *x, const float *scale, const float *shift, void *y, long long n, int C, int act,

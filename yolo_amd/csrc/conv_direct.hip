@@ -336,22 +336,37 @@ int launch_conv_direct(const ConvArgs &a, hipStream_t s) {
 // kernel [taps][Cout (its input channels)][src_cout (its output channels, <= Cin)], and the
 // packed kernel is that one flipped over the taps with the two channel axes swapped (rows of
 // zeros where Cin pads src_cout).
+struct PackGeom {
+    int K, Cin, Cout, Kw, rows, CB, kb, src_cout, ntaps;
+};
+__device__ __forceinline__ float pack_value(const float *__restrict__ w, const PackGeom &g, size_t i) {
+    const int co = (int)(i / g.Kw), kk = (int)(i - (size_t)co * g.Kw);
+    // packed column kk = blk*kb + tap*CB + c  <-  HWIO row tap*Cin + blk*CB + c
+    const int blk = kk / g.kb, rem = kk - blk * g.kb, tap = rem / g.CB, c = rem - tap * g.CB;
+    float v = 0.0f;
+    if (co < g.Cout && kk < g.K) {
+        const int ci = blk * g.CB + c;
+        if (g.src_cout == 0) v = w[(size_t)(tap * g.Cin + ci) * g.Cout + co];
+        else if (ci < g.src_cout) v = w[((size_t)(g.ntaps - 1 - tap) * g.Cout + co) * g.src_cout + ci];
+    }
+    return v;
+}
 template <typename T>
 __global__ void __launch_bounds__(256)
-pack_weights_kernel(const float *__restrict__ w, T *__restrict__ out, int K, int Cin, int Cout, int Kw, int rows,
-                    int CB, int kb, int src_cout, int ntaps) {
-    const size_t n = (size_t)rows * Kw;
+pack_weights_kernel(const float *__restrict__ w, T *__restrict__ out, PackGeom g) {
+    const size_t n = (size_t)g.rows * g.Kw;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        elem<T>::store(out + i, pack_value(w, g, i));
+}
+// The kernel of a layer packed both ways in one launch (what a training step needs after every
+// update of the weights): `fwd` for the layer itself, `bwd` for its input-gradient convolution.
+template <typename T>
+__global__ void __launch_bounds__(256)
+pack_weights_pair_kernel(const float *__restrict__ w, T *__restrict__ fwd, T *__restrict__ bwd, PackGeom gf, PackGeom gb) {
+    const size_t nf = (size_t)gf.rows * gf.Kw, n = nf + (size_t)gb.rows * gb.Kw;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int co = (int)(i / Kw), kk = (int)(i - (size_t)co * Kw);
-        // packed column kk = blk*kb + tap*CB + c  <-  HWIO row tap*Cin + blk*CB + c
-        const int blk = kk / kb, rem = kk - blk * kb, tap = rem / CB, c = rem - tap * CB;
-        float v = 0.0f;
-        if (co < Cout && kk < K) {
-            const int ci = blk * CB + c;
-            if (src_cout == 0) v = w[(size_t)(tap * Cin + ci) * Cout + co];
-            else if (ci < src_cout) v = w[((size_t)(ntaps - 1 - tap) * Cout + co) * src_cout + ci];
-        }
-        elem<T>::store(out + i, v);
+        if (i < nf) elem<T>::store(fwd + i, pack_value(w, gf, i));
+        else elem<T>::store(bwd + (i - nf), pack_value(w, gb, i - nf));
     }
 }
 // Direct path: same [K][Cout] fp32 layout; with bf16 compute the values are rounded
@@ -362,6 +377,13 @@ copy_weights_kernel(const float *__restrict__ w, float *__restrict__ out, size_t
         const float v = w[i];
         out[i] = round_bf16 ? bf16_to_f32(f32_to_bf16(v)) : v;
     }
+}
+
+static PackGeom pack_geom(int k, int Cin, int Cout, int src_cout) {
+    PackGeom g;
+    g.K = k * k * Cin; g.Cin = Cin; g.Cout = Cout; g.Kw = packed_kw(k, Cin); g.rows = packed_rows(Cout);
+    g.CB = conv_channel_block(Cin); g.kb = k * k * g.CB; g.src_cout = src_cout; g.ntaps = k * k;
+    return g;
 }
 
 int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype,
@@ -375,14 +397,30 @@ int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int
                            dtype == YMX_BF16 ? 1 : 0);
         return check_launch("copy_weights");
     }
-    const int Kw = packed_kw(k, Cin), rows = packed_rows(Cout), CB = conv_channel_block(Cin);
-    const size_t n = (size_t)rows * Kw;
+    const PackGeom g = pack_geom(k, Cin, Cout, src_cout);
+    const size_t n = (size_t)g.rows * g.Kw;
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     if (dtype == YMX_BF16)
-        hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, w_hwio, (bf16_t *)w_packed, K, Cin, Cout, Kw, rows, CB, k * k * CB, src_cout, k * k);
+        hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, w_hwio, (bf16_t *)w_packed, g);
     else
-        hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, s, w_hwio, (float *)w_packed, K, Cin, Cout, Kw, rows, CB, k * k * CB, src_cout, k * k);
+        hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, s, w_hwio, (float *)w_packed, g);
     return check_launch("pack_weights");
+}
+
+// forward pack of a k x k x Cin x Cout kernel and the pack of its input-gradient convolution
+// (dz_channels >= Cout input channels, Cin output channels) in one launch; MFMA layouts only
+int launch_pack_weights_pair(const float *w_hwio, void *w_fwd, void *w_bwd, int k, int Cin, int Cout, int dz_channels, int dtype,
+                             hipStream_t s) {
+    if (!conv_uses_mfma(Cin, dtype) || !conv_uses_mfma(dz_channels, dtype))
+        return fail(YMX_EUNSUPPORTED, "pack_weights_pair: %d / %d channels in dtype %d take the direct kernel", Cin, dz_channels, dtype);
+    const PackGeom gf = pack_geom(k, Cin, Cout, 0), gb = pack_geom(k, dz_channels, Cin, Cout);
+    const size_t n = (size_t)gf.rows * gf.Kw + (size_t)gb.rows * gb.Kw;
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    if (dtype == YMX_BF16)
+        hipLaunchKernelGGL((pack_weights_pair_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, w_hwio, (bf16_t *)w_fwd, (bf16_t *)w_bwd, gf, gb);
+    else
+        hipLaunchKernelGGL((pack_weights_pair_kernel<float>), dim3(grid), dim3(256), 0, s, w_hwio, (float *)w_fwd, (float *)w_bwd, gf, gb);
+    return check_launch("pack_weights_pair");
 }
 
 }  // namespace ymx

@@ -36,6 +36,13 @@ __device__ __forceinline__ uint32_t epi_pack2(f32x2_t v) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, epi_bf16x2_t));
 }
 
+// Output element types of the kernels: float, bf16_t, or this tag = bf16 outputs plus the
+// value before the activation as a second bf16 output (ConvArgs::z), the form a training
+// step's forward pass takes.  A kernel instantiated for the tag contains only that epilogue.
+struct bf16_zout_t { bf16_t v; };
+template <typename T> struct epi_out { typedef T type; static constexpr bool zout = false; };
+template <> struct epi_out<bf16_zout_t> { typedef bf16_t type; static constexpr bool zout = true; };
+
 // HQMAX = channels transposed at a time: 64 (128-byte output runs, 16 KB image per wave) or 32
 // (64-byte runs, 8 KB per wave: for kernels that trade run length for workgroups per CU).
 // NPX = pixels of the wave tile: 64, or 48 for the three-block tiles of conv_igemm_halo.hip.
@@ -78,10 +85,12 @@ __device__ __forceinline__ void epi_load_res(const ConvArgs &a, int half, int cb
 
 // rpre[0] must hold the first half's shortcut values if epi_res_pre(a); the second half
 // (128-channel wave tiles) is fetched here, while the first half goes out.
-template <typename OT, int NI, int NJ, int HQMAX = 64>
+template <typename OTAG, int NI, int NJ, int HQMAX = 64>
 __device__ __forceinline__ void epi_run(const ConvArgs &a, f32x4_t (&acc)[NI][NJ], char *tbase, int cbase, int pbase,
                                         int lane, epi_u32x4_t (&rpre)[EpiGeom<NI, HQMAX, 16 * NJ>::NH][EpiGeom<NI, HQMAX, 16 * NJ>::NPASS]) {
     typedef EpiGeom<NI, HQMAX, 16 * NJ> G;
+    typedef typename epi_out<OTAG>::type OT;
+    constexpr bool ZKERNEL = epi_out<OTAG>::zout;
     static_assert(NJ == 4 || NJ == 3, "wave tiles are 64 or 48 pixels wide");
     constexpr int HQ = G::HQ, NH = G::NH, SLOTS = G::SLOTS, LPP = G::LPP, PPI = G::PPI, NPASS = G::NPASS;
     OT *__restrict__ y = (OT *)a.y;
@@ -118,9 +127,10 @@ __device__ __forceinline__ void epi_run(const ConvArgs &a, f32x4_t (&acc)[NI][NJ
         }
     };
 
-    auto fast = [&](auto act_tag, auto res_tag) {
+    auto fast = [&](auto act_tag, auto res_tag, auto z_tag) {
         constexpr int ACT = decltype(act_tag)::value;
         constexpr bool RES = decltype(res_tag)::value;
+        constexpr bool ZOUT = decltype(z_tag)::value;          // also store the value before the activation (bf16)
 #pragma unroll
         for (int half = 0; half < NH; ++half) {
             float sc[8], sh[8];
@@ -144,10 +154,14 @@ __device__ __forceinline__ void epi_run(const ConvArgs &a, f32x4_t (&acc)[NI][NJ
                 // pairs of neighbouring channels stay pairs from the affine step to the packed
                 // conversion, so that no instruction is spent on re-pairing them
                 f32x2_t o[4];
+                uint32_t zq[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    o[r] = affine_act2<ACT>(f32x2_t{v[2 * r], v[2 * r + 1]}, f32x2_t{sc[2 * r], sc[2 * r + 1]},
-                                            f32x2_t{sh[2 * r], sh[2 * r + 1]});
+                for (int r = 0; r < 4; ++r) {
+                    const f32x2_t t = affine2(f32x2_t{v[2 * r], v[2 * r + 1]}, f32x2_t{sc[2 * r], sc[2 * r + 1]},
+                                              f32x2_t{sh[2 * r], sh[2 * r + 1]});
+                    if constexpr (ZOUT) zq[r] = epi_pack2(t);
+                    o[r] = act2<ACT>(t);
+                }
                 if constexpr (RES) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -159,6 +173,7 @@ __device__ __forceinline__ void epi_run(const ConvArgs &a, f32x4_t (&acc)[NI][NJ
                 }
                 if (p < a.P && co < a.Cout) {
                     OT *yp = y + (size_t)p * a.y_ld + co;
+                    if constexpr (ZOUT) store_stream16((bf16_t *)a.z + (size_t)p * a.Cout + co, zq[0], zq[1], zq[2], zq[3]);
                     if constexpr (sizeof(OT) == 2) {
                         store_stream16(yp, epi_pack2(o[0]), epi_pack2(o[1]), epi_pack2(o[2]), epi_pack2(o[3]));
                     } else {
@@ -171,12 +186,20 @@ __device__ __forceinline__ void epi_run(const ConvArgs &a, f32x4_t (&acc)[NI][NJ
         }
     };
     auto fast_act = [&](auto res_tag) {
-        if (a.act == YMX_ACT_MISH) fast(std::integral_constant<int, YMX_ACT_MISH>{}, res_tag);
-        else if (a.act == YMX_ACT_LEAKY) fast(std::integral_constant<int, YMX_ACT_LEAKY>{}, res_tag);
-        else fast(std::integral_constant<int, YMX_ACT_NONE>{}, res_tag);
+        if (a.act == YMX_ACT_MISH) fast(std::integral_constant<int, YMX_ACT_MISH>{}, res_tag, std::false_type{});
+        else if (a.act == YMX_ACT_LEAKY) fast(std::integral_constant<int, YMX_ACT_LEAKY>{}, res_tag, std::false_type{});
+        else fast(std::integral_constant<int, YMX_ACT_NONE>{}, res_tag, std::false_type{});
+    };
+    // with the second output (training forward): the two activations a derivative exists for
+    auto fast_z = [&](auto res_tag) {
+        if (a.act == YMX_ACT_MISH) fast(std::integral_constant<int, YMX_ACT_MISH>{}, res_tag, std::true_type{});
+        else fast(std::integral_constant<int, YMX_ACT_LEAKY>{}, res_tag, std::true_type{});
     };
 
-    if (epi_vec_ok(a) && res == nullptr) {
+    if constexpr (ZKERNEL) {                     // the launcher guarantees epi_vec_ok, a.z and Mish / leaky
+        if (res == nullptr) fast_z(std::false_type{});
+        else fast_z(std::true_type{});
+    } else if (epi_vec_ok(a) && res == nullptr) {
         fast_act(std::false_type{});
     } else if (epi_res_pre(a)) {
         fast_act(std::true_type{});

@@ -177,6 +177,7 @@ static int launch_dma_cfg(const ConvArgs &a, hipStream_t s) {
 // bf16 operands only; out_dtype bf16 or f32.
 int launch_conv_igemm_dma(const ConvArgs &a, hipStream_t s) {
     if (a.dtype != YMX_BF16) return fail(YMX_EUNSUPPORTED, "conv_igemm_dma: bf16 operands only");
+    if (a.z) return launch_dma_cfg<bf16_zout_t, 256>(a, s);
     if (a.out_dtype == YMX_BF16) return launch_dma_cfg<bf16_t, 256>(a, s);
     return launch_dma_cfg<float, 256>(a, s);
 }

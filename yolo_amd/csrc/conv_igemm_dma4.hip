@@ -292,6 +292,7 @@ static int launch_dma4_cfg(const ConvArgs &a, hipStream_t s) {
 // bf16 operands only; out_dtype bf16 or f32.
 int launch_conv_igemm_dma4(const ConvArgs &a, hipStream_t s) {
     if (a.dtype != YMX_BF16) return fail(YMX_EUNSUPPORTED, "conv_igemm_dma4: bf16 operands only");
+    if (a.z) return launch_dma4_cfg<bf16_zout_t>(a, s);
     if (a.out_dtype == YMX_BF16) return launch_dma4_cfg<bf16_t>(a, s);
     return launch_dma4_cfg<float>(a, s);
 }

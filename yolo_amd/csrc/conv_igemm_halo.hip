@@ -366,9 +366,11 @@ static int launch_halo_cfg(const ConvArgs &a, hipStream_t s) {
 int launch_conv_igemm_halo(const ConvArgs &a, hipStream_t s) {
     if (!conv_halo_eligible(a)) return fail(YMX_EUNSUPPORTED, "conv_igemm_halo: shape not supported");
     if (conv_halo_tile_pixels(a) == 192) {
+        if (a.z) return launch_halo_cfg<bf16_zout_t, 3>(a, s);
         if (a.out_dtype == YMX_BF16) return launch_halo_cfg<bf16_t, 3>(a, s);
         return launch_halo_cfg<float, 3>(a, s);
     }
+    if (a.z) return launch_halo_cfg<bf16_zout_t, 4>(a, s);
     if (a.out_dtype == YMX_BF16) return launch_halo_cfg<bf16_t, 4>(a, s);
     return launch_halo_cfg<float, 4>(a, s);
 }

@@ -190,9 +190,11 @@ static int launch_slab2_cfg(const ConvArgs &a, hipStream_t s) {
 int launch_conv_igemm_slab2(const ConvArgs &a, hipStream_t s) {
     if (!conv_slab2_eligible(a)) return fail(YMX_EUNSUPPORTED, "conv_igemm_slab2: shape not supported");
     if (a.Cin == 32) {
+        if (a.z) return launch_slab2_cfg<bf16_zout_t, 32>(a, s);
         if (a.out_dtype == YMX_BF16) return launch_slab2_cfg<bf16_t, 32>(a, s);
         return launch_slab2_cfg<float, 32>(a, s);
     }
+    if (a.z) return launch_slab2_cfg<bf16_zout_t, 64>(a, s);
     if (a.out_dtype == YMX_BF16) return launch_slab2_cfg<bf16_t, 64>(a, s);
     return launch_slab2_cfg<float, 64>(a, s);
 }

@@ -232,8 +232,7 @@ act_bwd_bias_kernel(const uint4 *__restrict__ z, const uint4 *__restrict__ dy, u
     __shared__ float red[256 * 8];
     const int nch = C >> 3, t = threadIdx.x;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (size_t i = (size_t)blockIdx.x * 256 + t; i < n8; i += (size_t)gridDim.x * 256) {
-        const uint4 zv = z[i], ov = dy[i];
+    auto one = [&](const uint4 zv, const uint4 ov) {
         const uint32_t zw[4] = {zv.x, zv.y, zv.z, zv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
         uint32_t r[4];
 #pragma unroll
@@ -246,8 +245,17 @@ act_bwd_bias_kernel(const uint4 *__restrict__ z, const uint4 *__restrict__ dy, u
             acc[2 * k] += __uint_as_float(r[k] << 16);
             acc[2 * k + 1] += __uint_as_float(r[k] & 0xffff0000u);
         }
-        dz[i] = make_uint4(r[0], r[1], r[2], r[3]);
+        return make_uint4(r[0], r[1], r[2], r[3]);
+    };
+    // two chunks of the strided walk per iteration: four 16-byte loads in flight per thread
+    const size_t step = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + t;
+    for (; i + step < n8; i += 2 * step) {
+        const uint4 za = z[i], oa = dy[i], zb = z[i + step], ob = dy[i + step];
+        dz[i] = one(za, oa);
+        dz[i + step] = one(zb, ob);
     }
+    if (i < n8) dz[i] = one(z[i], dy[i]);
 #pragma unroll
     for (int k = 0; k < 8; ++k) red[t * 8 + k] = acc[k];
     __syncthreads();

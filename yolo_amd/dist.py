@@ -84,62 +84,133 @@ def all_gather_detections(det, global_batch, group=None):
 
 class GradientBuckets(object):
     """Data-parallel gradient averaging for a training step (the exchange a batch-sharded
-    training run needs; the reference has no multi-device code).
+    training run needs; the reference has no multi-device code), overlapped with the
+    backward pass.
 
     The gradients of ``params`` live in a few large flat buffers (``bucket_bytes`` each,
-    filled in reverse parameter order, the order back-propagation produces them);
-    ``p.grad`` of every parameter is a view into its bucket, so nothing is copied before or
-    after the collective.  ``reduce()`` starts one asynchronous all-reduce per bucket and
-    ``wait()`` finishes them and divides by the world size.  On RCCL a ring all-reduce moves
-    2 (n-1)/n of a bucket over each GPU's xGMI links; 64 MiB buckets keep the six collectives
-    of an 88 M-parameter fp32 model bandwidth-bound (about 0.5 ms each at 150 GB/s per link)
-    while leaving the first ones free to overlap with the rest of the backward pass."""
+    filled in reverse parameter order, the order back-propagation produces them; every
+    parameter starts on a 256-byte boundary); ``p.grad`` of every parameter is a view into
+    its bucket, so nothing is copied before or after the collective.  A bucket's
+    asynchronous all-reduce starts the moment its last gradient is final, while the rest of
+    the backward pass still runs:
 
-    def __init__(self, params, bucket_bytes=64 << 20, group=None):
+      * yolo_amd.training's convolution blocks write their weight and bias gradients
+        straight into the views (``p._grad_bucket``) and call ``ready(p)``;
+      * for any other parameter a post-accumulate-grad hook calls ``ready(p)`` once autograd
+        has added its gradient into the view.
+
+    Buckets start in index order (a bucket whose turn has not come waits for the ones before
+    it), so every rank issues the same collectives in the same order whatever order its
+    gradients arrive in.  Per step::
+
+        buckets.begin()          # zero the buffers, forget last step's state
+        loss.backward()          # all-reduces start as buckets fill
+        buckets.wait()           # starts what is left, finishes all; .grad = mean over ranks
+
+    On RCCL a ring all-reduce moves 2 (n-1)/n of a bucket over each GPU's xGMI links; 64 MiB
+    buckets keep the six collectives of an 88 M-parameter fp32 model bandwidth-bound (about
+    0.5 ms each at 150 GB/s per link) and the first five hide behind the backward pass."""
+
+    ALIGN = 64                                  # elements: 256 bytes of fp32
+
+    def __init__(self, params, bucket_bytes=64 << 20, group=None, hooks=True):
         self.group = group
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []                       # flat tensors
-        self._handles = []
+        self.members = []                       # per bucket: its parameters
+        self.launch_order = []                  # bucket indices in the order their collectives started (this step)
+        self._where = {}                        # id(param) -> bucket index
+        self._pending = []                      # per bucket: ids of parameters not ready yet
+        self._handles = {}                      # bucket index -> (work, reduced tensor)
+        self._next = 0                          # first bucket not started yet
+        self._hooks = []
         order = list(reversed(self.params))
         i = 0
         while i < len(order):
             dtype, device = order[i].dtype, order[i].device
-            chunk, size = [], 0
+            chunk, offs, size = [], [], 0
             while i < len(order) and order[i].dtype == dtype and order[i].device == device and \
                     (not chunk or (size + order[i].numel()) * order[i].element_size() <= bucket_bytes):
                 chunk.append(order[i])
-                size += order[i].numel()
+                offs.append(size)
+                size += -(-order[i].numel() // self.ALIGN) * self.ALIGN
                 i += 1
             flat = torch.zeros((size,), dtype=dtype, device=device)
-            off = 0
-            for p in chunk:
-                p.grad = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
+            for p, off in zip(chunk, offs):
+                view = flat[off:off + p.numel()].view_as(p)
+                p.grad = view
+                p._grad_bucket = (self, view)
+                self._where[id(p)] = len(self.buckets)
             self.buckets.append(flat)
+            self.members.append(chunk)
+        if hooks:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self.ready))
+        self.begin(zero=False)
 
-    def zero_(self):
-        for b in self.buckets:
-            b.zero_()
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def begin(self, zero=True):
+        """Start of a step: gradients zeroed (autograd adds into them), nothing ready."""
+        if self._handles:
+            raise RuntimeError("GradientBuckets.begin: the previous step's collectives were not waited for")
+        if zero:
+            for b in self.buckets:
+                b.zero_()
+        self._pending = [set(id(p) for p in chunk) for chunk in self.members]
+        self._next = 0
+        self.launch_order = []
+        return self
+
+    zero_ = begin
+
+    def _start(self, i):
+        b = self.buckets[i]
+        self.launch_order.append(i)
+        if not self._active():
+            return
+        t = b
+        nccl = dist.get_backend(self.group) == "nccl"
+        if b.is_cuda and not nccl:
+            t = b.cpu()                         # rehearsal backends reduce host tensors
+        op = dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM
+        self._handles[i] = (dist.all_reduce(t, op=op, group=self.group, async_op=True), t, nccl)
+
+    def ready(self, p):
+        """The gradient of ``p`` is final for this step (safe to call from the autograd thread)."""
+        i = self._where.get(id(p))
+        if i is None:
+            raise ValueError("GradientBuckets.ready: not one of this object's parameters")
+        self._pending[i].discard(id(p))
+        while self._next < len(self.buckets) and not self._pending[self._next]:
+            self._start(self._next)
+            self._next += 1
 
     def reduce(self):
-        """Start the all-reduce of every bucket (in the order the backward pass fills them)."""
-        if not (dist.is_available() and dist.is_initialized()):
-            return self
-        for b in self.buckets:
-            t = b
-            if b.is_cuda and dist.get_backend(self.group) != "nccl":
-                t = b.cpu()                     # rehearsal backends reduce host tensors
-            self._handles.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), t, b))
+        """Start the all-reduce of every bucket that has not started yet (parameters that took
+        no part in the step, or a backward pass that does not report readiness)."""
+        while self._next < len(self.buckets):
+            self._start(self._next)
+            self._next += 1
         return self
 
     def wait(self):
         """Finish the collectives; gradients become the average over the ranks."""
-        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
-        for h, t, b in self._handles:
+        self.reduce()
+        world = dist.get_world_size(self.group) if self._active() else 1
+        for i in sorted(self._handles):
+            h, t, averaged = self._handles[i]
             h.wait()
+            b = self.buckets[i]
             if t is not b:
                 b.copy_(t)
-            if world > 1:
+            if world > 1 and not averaged:
                 b.div_(world)
-        self._handles = []
+        self._handles = {}
         return self
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

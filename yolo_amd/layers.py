@@ -233,6 +233,36 @@ class YOLOConv(nn.Module):
         self._packed["entry"] = (key, entry)
         return entry
 
+    def packed_training(self, dtype):
+        """(forward pack, shift, pack of the input-gradient convolution or None) for a training
+        step: both layouts come out of one launch (ymx_pack_weights_pair) and are kept until
+        the kernel or the bias changes, i.e. for the forward and the backward pass of a step.
+        Layers whose input channels do not take the MFMA kernels (the first: 3) have no
+        input-gradient pack."""
+        if self.batch_normalization:
+            raise ValueError("YOLOConv.packed_training: batch normalisation layers are not trained")
+        dev = self.kernel.device
+        key = (dtype, dev, self.kernel._version, self.bias._version)
+        hit = self._packed.get("train")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        k, cin, cout = self.kernel_size, self.in_channels, self.filters
+        if cin % 8:
+            wp, _, shift, _ = self.packed(dtype)
+            entry = (wp, shift, None)
+        else:
+            _lib.require_gpu(self.kernel)
+            L = _lib.lib()
+            code = _lib.dtype_code(dtype)
+            coutp = -(-cout // 8) * 8
+            wp = torch.empty(L.ymx_packed_weight_bytes(k, cin, cout, code), dtype=torch.uint8, device=dev)
+            wdp = torch.empty(L.ymx_packed_weight_bytes(k, coutp, cin, code), dtype=torch.uint8, device=dev)
+            src = self.kernel.detach().float().contiguous()
+            _lib.launch("ymx_pack_weights_pair", wp, _lib.ptr(src), _lib.ptr(wp), _lib.ptr(wdp), k, cin, cout, coutp, code)
+            entry = (wp, self.bias.detach().float().contiguous(), wdp, src)
+        self._packed["train"] = (key, entry)
+        return entry
+
     # -- geometry ---------------------------------------------------------------
     def output_hw(self, h, w):
         if not self.downsample:

@@ -6,8 +6,8 @@ graph (which tensor feeds which, summing gradients where a tensor is used twice,
 shortcut of a ResidialBlock); every forward and backward step of a block is a launch of
 libymx:
 
-  forward   z = conv(x) + bias            ymx_conv2d_fused_ex, no activation (z is kept)
-            y = act(z) + shortcut         ymx_act_apply
+  forward   z = conv(x) + bias            } ymx_conv2d_fused_z: both outputs of one launch
+            y = act(z) + shortcut         } (z is kept for the derivative)
   backward  dz = dy * act'(z)             ymx_act_backward
             dbias = sum_p dz              ymx_bias_grad
             dkernel = x (*) dz            ymx_conv_wgrad (HWIO fp32, the kernel's own layout)
@@ -67,6 +67,39 @@ def _apply_options():
         _lib.check(L.ymx_set_option(name.encode(), int(value)))
 
 
+class L2Regulariser(object):
+    """The kernel regulariser of the reference's convolutions: every YOLOConv adds
+    ``coefficient * sum(kernel ** 2)`` to the loss Keras minimises (kernel_regularizer =
+    l2(0.0005), /root/reference/layers.py:61; biases are not regularised), i.e.
+    ``2 * coefficient * kernel`` to each kernel's gradient.
+
+        reg = L2Regulariser(model)            # every YOLOConv kernel below `model`
+        loss.backward()
+        reg.add_gradients_()                  # .grad += 2 * coefficient * kernel, one fused launch per chunk of tensors
+        total = loss + reg.penalty()          # the number Keras reports
+
+    With data-parallel gradient averaging call add_gradients_() after the averaging (the term
+    is the same on every rank)."""
+
+    def __init__(self, model_or_kernels, coefficient=0.0005):
+        from .layers import YOLOConv
+        if isinstance(model_or_kernels, torch.nn.Module):
+            self.kernels = [m.kernel for m in model_or_kernels.modules() if isinstance(m, YOLOConv) and m.in_channels is not None]
+        else:
+            self.kernels = list(model_or_kernels)
+        self.coefficient = float(coefficient)
+
+    def penalty(self):
+        with torch.no_grad():
+            norms = torch._foreach_norm([k.detach() for k in self.kernels])
+            return self.coefficient * torch.stack(norms).double().square().sum()
+
+    def add_gradients_(self):
+        ks = [k for k in self.kernels if k.grad is not None]
+        with torch.no_grad():
+            torch._foreach_add_([k.grad for k in ks], [k.detach() for k in ks], alpha=2.0 * self.coefficient)
+
+
 overlap_wgrad = True        # weight gradients on a second HIP stream, next to the input gradients
 _side = {}
 
@@ -77,6 +110,11 @@ def _side_stream(device):
     if st is None:
         st = _side[key] = torch.cuda.Stream(device=device)
     return st
+
+
+def _slot(param):
+    """(GradientBuckets, view of the parameter's place in its bucket) or None."""
+    return getattr(param, "_grad_bucket", None)
 
 
 def _empty(shape, like, dtype=None):
@@ -126,15 +164,23 @@ class _ConvBlock(torch.autograd.Function):
         x = x.contiguous()
         if cin % 8 == 0 and x.dtype != cdt:
             x = x.to(cdt)
-        entry = layer.packed(cdt)
-        wp, shift = entry[0], entry[2]
-        z = _conv(x, wp, shift, cin, cout, k, stride, cdt, cdt)
-        if layer.act_code != _lib.ACT_NONE or shortcut is not None:
+        entry = layer.packed_training(cdt)
+        wp, shift = entry[0], entry[1]
+        sc = None if shortcut is None else shortcut.to(cdt).contiguous()
+        if layer.act_code != _lib.ACT_NONE:
+            b, h, w, _ = x.shape
+            oh, ow = layer.output_hw(h, w)
+            z = _empty((b, oh, ow, cout), x, cdt)
             y = torch.empty_like(z)
-            sc = None if shortcut is None else shortcut.to(cdt).contiguous()
-            _lib.launch("ymx_act_apply", z, _lib.ptr(z), _lib.ptr(sc), _lib.ptr(y), z.numel(), layer.act_code, _lib.dtype_code(cdt))
+            _lib.launch("ymx_conv2d_fused_z", x, _lib.ptr(x), _lib.ptr(wp), None, _lib.ptr(shift), _lib.ptr(sc), _lib.ptr(y), _lib.ptr(z),
+                        b, h, w, cin, cout, k, stride, layer.act_code, _lib.dtype_code(x.dtype))
         else:
-            y = z
+            z = _conv(x, wp, shift, cin, cout, k, stride, cdt, cdt)
+            if sc is not None:
+                y = torch.empty_like(z)
+                _lib.launch("ymx_act_apply", z, _lib.ptr(z), _lib.ptr(sc), _lib.ptr(y), z.numel(), layer.act_code, _lib.dtype_code(cdt))
+            else:
+                y = z
         ctx.save_for_backward(x, z, kernel)
         ctx.layer = layer
         ctx.has_shortcut = shortcut is not None
@@ -158,11 +204,16 @@ class _ConvBlock(torch.autograd.Function):
         _apply_options()
         npix = b * oh * ow
         dbias = None
+        # gradient buckets (yolo_amd.dist.GradientBuckets): the kernels write a parameter's
+        # gradient straight into its place in the bucket and report it ready, which starts the
+        # bucket's all-reduce as soon as its last gradient is there; autograd gets None
+        kslot = _slot(layer.kernel) if ctx.needs_input_grad[1] else None
+        bslot = _slot(layer.bias) if ctx.needs_input_grad[2] else None
         if layer.act_code != _lib.ACT_NONE:
             dz = torch.empty_like(z)
             nb = L.ymx_act_backward_bias_workspace_bytes(npix, cout, layer.act_code, code) if ctx.needs_input_grad[2] else 0
             if nb:                       # derivative of the activation and the bias gradient in one pass
-                dbias = torch.empty((cout,), device=x.device, dtype=torch.float32)
+                dbias = bslot[1] if bslot is not None else torch.empty((cout,), device=x.device, dtype=torch.float32)
                 ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)
                 _lib.launch("ymx_act_backward_bias", z, _lib.ptr(z), _lib.ptr(dy), _lib.ptr(dz), npix, cout, layer.act_code, code,
                             _lib.ptr(dbias), _lib.ptr(ws), nb)
@@ -179,12 +230,18 @@ class _ConvBlock(torch.autograd.Function):
             ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)
             _lib.launch("ymx_bias_grad", dzp, _lib.ptr(dzp), npix, coutp, 0, code, _lib.ptr(dbp), _lib.ptr(ws), nb)
             dbias = dbp[:cout]
+            if bslot is not None:
+                bslot[1].copy_(dbias)
+        if bslot is not None:
+            bslot[0].ready(layer.bias)
+            dbias = None
         dkernel = None
         side = None
         if ctx.needs_input_grad[1]:
             xp = _pad_channels(x.to(cdt))
             cinp = xp.shape[-1]
-            dwp = torch.empty((k, k, cinp, coutp), device=x.device, dtype=torch.float32)
+            direct = kslot is not None and cinp == cin and coutp == cout
+            dwp = kslot[1] if direct else torch.empty((k, k, cinp, coutp), device=x.device, dtype=torch.float32)
             nb = L.ymx_conv_wgrad_workspace_bytes(b, h, w, cinp, coutp, k, stride)
             ws = torch.empty((max(nb, 16),), device=x.device, dtype=torch.uint8)
             if trace is not None:
@@ -206,9 +263,9 @@ class _ConvBlock(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             # d loss / d x = conv(dz, kernel flipped over the taps, input and output channels swapped)
-            src_k = kernel.detach().float().contiguous()
-            wdp = torch.empty(L.ymx_packed_weight_bytes(k, coutp, cin, code), dtype=torch.uint8, device=x.device)
-            _lib.launch("ymx_pack_weights_dgrad", wdp, _lib.ptr(src_k), _lib.ptr(wdp), k, cin, cout, coutp, code)
+            wdp = layer.packed_training(cdt)[2]                   # packed with the forward kernel, in the same launch
+            if wdp is None:
+                raise ValueError("yolo_amd.training: no input gradient for a layer of %d input channels" % cin)
             src = dzp
             if stride == 2:
                 if k != 3:
@@ -228,7 +285,12 @@ class _ConvBlock(torch.autograd.Function):
                 torch.cuda.current_stream(x.device).wait_stream(side)
             # (handed over as it is where nothing was padded: autograd keeps a tensor that is not a
             # view as the parameter's .grad without copying it)
-            dkernel = dwp if (cinp == cin and coutp == cout) else dwp[:, :, :cin, :cout].contiguous()
+            if kslot is not None:
+                if not direct:
+                    kslot[1].copy_(dwp[:, :, :cin, :cout])
+                kslot[0].ready(layer.kernel)
+            else:
+                dkernel = dwp if (cinp == cin and coutp == cout) else dwp[:, :, :cin, :cout].contiguous()
         dshortcut = None
         if ctx.has_shortcut and ctx.needs_input_grad[3]:
             if ctx.link is not None and ctx.shortcut_dtype == cdt:
