@@ -368,18 +368,18 @@ def test_detector_training_step_vs_oracle():
     assert float(np.median(err)) < 2e-2 and max(err) < 6e-2
 
 
-Z_CASES = [   # B, H, W, Cin, Cout, k, stride, act, shortcut  -> the kernel family the shape is routed to
-    (8, 52, 52, 512, 1024, 3, 1, 2, False),      # resident-slab kernel, 256-pixel tiles
-    (8, 52, 52, 128, 256, 3, 1, 2, True),        # the same with the shortcut
-    (16, 13, 13, 512, 1024, 3, 1, 1, False),     # 192-pixel tiles
-    (8, 52, 52, 1024, 512, 1, 1, 2, False),      # phase-staggered kernel
-    (8, 52, 52, 256, 512, 3, 2, 1, False),       # stride 2
-    (4, 208, 208, 64, 32, 1, 1, 2, False),       # narrow LDS-DMA kernel
-    (4, 208, 208, 32, 64, 3, 1, 2, True),        # narrow input-slab kernel, shortcut
-    (4, 104, 104, 128, 64, 1, 1, 1, False),
-    (1, 13, 13, 256, 512, 3, 1, 2, True),        # too few tiles: register-staged kernel, two launches
-    (2, 20, 24, 40, 72, 3, 1, 2, False),         # channel counts off the tile sizes
-    (2, 64, 64, 3, 32, 3, 1, 2, False),          # first layer (fp32 images, direct kernel): two launches
+Z_CASES = [   # B, H, W, Cin, Cout, k, stride, act, shortcut, the kernel family the shape is routed to
+    (64, 26, 26, 512, 1024, 3, 1, 2, False, "halo"),      # resident-slab kernel, 256-pixel tiles
+    (16, 52, 52, 128, 256, 3, 1, 2, True, "halo"),        # the same with the shortcut
+    (64, 13, 13, 512, 1024, 3, 1, 1, False, "halo192"),   # 192-pixel tiles
+    (8, 52, 52, 1024, 512, 1, 1, 2, False, "dma4"),       # phase-staggered kernel
+    (32, 52, 52, 256, 512, 3, 2, 1, False, "dma4"),       # stride 2
+    (4, 208, 208, 64, 32, 1, 1, 2, False, "dma2"),        # narrow LDS-DMA kernel
+    (4, 208, 208, 32, 64, 3, 1, 2, True, "slab2"),        # narrow input-slab kernel, shortcut
+    (4, 104, 104, 128, 64, 1, 1, 1, False, "dma2"),
+    (1, 13, 13, 256, 512, 3, 1, 2, True, "igemm"),        # too few tiles: register-staged kernel, two launches
+    (2, 20, 24, 40, 72, 3, 1, 2, False, "igemm"),         # channel counts off the tile sizes
+    (2, 64, 64, 3, 32, 3, 1, 2, False, "direct"),         # first layer (fp32 images): two launches
 ]
 
 
@@ -390,7 +390,7 @@ def test_training_forward_two_outputs(case):
     convolution without activation, for every kernel family and for the shapes that run as
     two launches."""
     from yolo_amd import _lib
-    B, H, W, cin, cout, k, stride, act, use_sc = Z_CASES[case]
+    B, H, W, cin, cout, k, stride, act, use_sc, family = Z_CASES[case]
     L = _lib.lib()
     g = torch.Generator().manual_seed(900 + case)
     first = cin % 8 != 0
@@ -419,7 +419,16 @@ def test_training_forward_two_outputs(case):
                 B, H, W, cin, cout, k, stride, act, xd)
     torch.cuda.synchronize()
     assert torch.equal(z.view(torch.int16), want_z.view(torch.int16))
-    if first or (B, H) == (1, 13):
+    op = _lib.ymx_op()
+    op.kind, op.B, op.H, op.W, op.Cin, op.Cout, op.k, op.stride = 1, B, H, W, cin, cout, k, stride
+    op.dtype = op.out_dtype = code
+    op.x_dtype = xd
+    op.x, op.w, op.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
+    import ctypes
+    label = L.ymx_conv_kernel_label(ctypes.byref(op)).decode()
+    print("kernel family:", label)
+    assert label.startswith(family) or (family == "direct" and label == "first_rows")
+    if label in ("igemm", "direct", "first_rows"):
         # two launches: y = act(z rounded to bf16) + shortcut, one rounding more than the fused epilogue
         ref = want_y.float()
         assert float((y.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
