@@ -347,9 +347,25 @@ int ymx_pack_weights_dgrad(const float *w_hwio, void *w_packed, int k, int Cin, 
                            int dtype, void *stream);
 /* ymx_pack_weights (into w_fwd) and ymx_pack_weights_dgrad (into w_dgrad) of one kernel in one
  * launch: what a training step does for every layer after each update of the weights.  Cin and
- * dz_channels must take the MFMA kernels (multiples of 8 for bf16, of 4 for fp32). */
+ * dz_channels must take the MFMA kernels (multiples of 8 for bf16, of 4 for fp32).  stride 2
+ * (3x3, bf16): w_dgrad receives the form of ymx_pack_weights_dgrad_s2 below instead. */
 int ymx_pack_weights_pair(const float *w_hwio, void *w_fwd, void *w_dgrad, int k, int Cin, int Cout,
-                          int dz_channels, int dtype, void *stream);
+                          int dz_channels, int stride, int dtype, void *stream);
+/* Input gradient of a 3x3 stride-2 layer (layers.py:46-54: one zero row / column on the top / left,
+ * VALID) without spreading dz over a zero map: input pixel (2 i + ph, 2 j + pw) only meets the
+ * outputs (i + dr, j + dc), dr, dc in {0, 1}, so dx is a 2x2 convolution over dz with 4 Cin
+ * output channels (one block of Cin per parity (ph, pw)) whose results are scattered
+ * depth-to-space: 16 of the 36 multiply-adds per pixel the zero-map form spends (9 carry
+ * kernel taps, the other 7 blocks of the packed kernel are zero).  ymx_pack_weights_dgrad_s2
+ * packs that kernel from the forward HWIO fp32 kernel [3][3][Cin][Cout] (Cin a multiple of 8;
+ * ymx_packed_weight_bytes(2, dz_channels, 4 * Cin, dtype) bytes; ymx_pack_weights_pair with
+ * stride = 2 writes the same bytes); ymx_conv2d_dgrad_s2 writes dx [B,H,W,Cin] bf16 from dz
+ * [B,OH,OW,dz_channels] bf16, OH = H / 2, OW = W / 2 (rounded down: the last row / column of an
+ * odd-sized input takes no part in the forward pass; the caller zeroes it). */
+int ymx_pack_weights_dgrad_s2(const float *w_hwio, void *w_packed, int Cin, int Cout, int dz_channels,
+                              int dtype, void *stream);
+int ymx_conv2d_dgrad_s2(const void *dz, const void *w_packed, void *dx, int B, int OH, int OW,
+                        int dz_channels, int Cin, int H, int W, void *stream);
 /* Training forward of a convolution block (/root/reference/layers.py:41-90 with the value in
  * front of the activation kept for the derivative): z = conv(x) * scale + shift rounded to bf16
  * [B,H',W',Cout], y = act(conv(x) * scale + shift) + residual (bf16, the same bits as

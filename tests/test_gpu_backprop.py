@@ -448,7 +448,7 @@ def test_weight_packs_of_a_training_step_in_one_launch():
         f0, b0, f1, b1 = (torch.full((n,), 0x5a, dtype=torch.uint8, device=DEV) for n in (nf, nb, nf, nb))
         _lib.launch("ymx_pack_weights", f0, _lib.ptr(wt), _lib.ptr(f0), k, cin, cout, code)
         _lib.launch("ymx_pack_weights_dgrad", b0, _lib.ptr(wt), _lib.ptr(b0), k, cin, cout, coutp, code)
-        _lib.launch("ymx_pack_weights_pair", f1, _lib.ptr(wt), _lib.ptr(f1), _lib.ptr(b1), k, cin, cout, coutp, code)
+        _lib.launch("ymx_pack_weights_pair", f1, _lib.ptr(wt), _lib.ptr(f1), _lib.ptr(b1), k, cin, cout, coutp, 1, code)
         assert torch.equal(f0, f1) and torch.equal(b0, b1), (k, cin, cout)
 
 
@@ -502,3 +502,55 @@ def test_gradient_buckets_receive_the_block_gradients_in_place():
             assert torch.equal(m.bias.grad, want[j])
     pen = float(reg.penalty())
     assert abs(pen - 0.0005 * sum(float(k.detach().double().square().sum()) for k in reg.kernels)) < 1e-6 * pen
+
+
+S2_CASES = [   # B, H, W, Cin, Cout -> kernel family of the 2x2 depth-to-space convolution
+    (4, 208, 208, 64, 128, "dma4"),       # 4 * 64 = 256 output channels: phase-staggered kernel
+    (4, 416, 416, 32, 64, "dma2"),        # 128 output channels: narrow LDS-DMA kernel
+    (16, 52, 52, 256, 512, "dma4"),
+    (2, 30, 26, 16, 40, "igemm"),         # register-staged kernel; dz stored with 40 channels
+    (1, 15, 13, 8, 255, "igemm"),         # odd sizes (last row / column without gradient), 255 -> 256 dz channels
+]
+
+
+@pytest.mark.parametrize("case", range(len(S2_CASES)))
+def test_stride2_input_gradient_depth_to_space(case):
+    """ymx_pack_weights_dgrad_s2 + ymx_conv2d_dgrad_s2 through the C ABI against the fp32 CPU
+    derivative of the oracle's stride-2 convolution with respect to its input (same bf16
+    inputs; 1e-2 of the gradient's scale: bf16 output rounding)."""
+    import ctypes
+    from yolo_amd import _lib
+    B, H, W, cin, cout, family = S2_CASES[case]
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(1200 + case)
+    wt = N.bf16_round(torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5)
+    xo = torch.zeros(B, H, W, cin, requires_grad=True)
+    yo = N.yolo_conv(xo, {"kernel": wt, "bias": torch.zeros(cout)}, True, None)
+    oh, ow = yo.shape[1], yo.shape[2]
+    dz = N.bf16_round(torch.randn(B, oh, ow, cout, generator=g))
+    (yo * dz).sum().backward()
+    coutp = -(-cout // 8) * 8
+    dzp = torch.zeros(B, oh, ow, coutp, dtype=torch.bfloat16, device=DEV)
+    dzp[..., :cout] = dz.to(DEV)
+    code = _lib.BF16
+    wg = wt.to(DEV)
+    wp = torch.empty(L.ymx_packed_weight_bytes(2, coutp, 4 * cin, code), dtype=torch.uint8, device=DEV)
+    _lib.launch("ymx_pack_weights_dgrad_s2", wp, _lib.ptr(wg), _lib.ptr(wp), cin, cout, coutp, code)
+    # the pair pack writes the same bytes
+    wf = torch.empty(L.ymx_packed_weight_bytes(3, cin, cout, code), dtype=torch.uint8, device=DEV)
+    wp2 = torch.empty_like(wp)
+    _lib.launch("ymx_pack_weights_pair", wp2, _lib.ptr(wg), _lib.ptr(wf), _lib.ptr(wp2), 3, cin, cout, coutp, 2, code)
+    assert torch.equal(wp, wp2)
+    dx = torch.zeros(B, H, W, cin, dtype=torch.bfloat16, device=DEV)
+    dx[:, :2 * oh, :2 * ow] = float("nan")                  # every element of the covered region must be written
+    _lib.launch("ymx_conv2d_dgrad_s2", dzp, _lib.ptr(dzp), _lib.ptr(wp), _lib.ptr(dx), B, oh, ow, coutp, cin, H, W)
+    torch.cuda.synchronize()
+    op = _lib.ymx_op()
+    op.kind, op.B, op.H, op.W, op.Cin, op.Cout, op.k, op.stride = 1, B, oh, ow, coutp, 4 * cin, 1, 1
+    op.dtype = op.out_dtype = op.x_dtype = code
+    op.x, op.w, op.y = dzp.data_ptr(), wp.data_ptr(), dx.data_ptr()
+    label = L.ymx_conv_kernel_label(ctypes.byref(op)).decode()      # (asked for a 1x1 of the same size: the same routing)
+    assert label == family, label
+    e = _scaled_err(dx.float().cpu(), xo.grad)
+    print("stride-2 input gradient, %s: error %.2e of the gradient's scale" % (family, e))
+    assert e < 1e-2

@@ -52,6 +52,8 @@ def main():
     if os.environ.get("OVERLAP"):
         T.overlap_wgrad = bool(int(os.environ["OVERLAP"]))
 
+    reg = T.L2Regulariser(det)
+
     def step():
         with T.backprop():
             s, m, l = head(*backbone(x))
@@ -59,6 +61,7 @@ def main():
         for p in params:
             p.grad = None
         loss.backward()
+        reg.add_gradients_()
         with torch.no_grad():
             torch._foreach_add_(params, [p.grad for p in params], alpha=-lr)
         return loss

@@ -35,7 +35,9 @@ SIGNATURES = {
     "ymx_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "ymx_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ymx_pack_weights_dgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "ymx_pack_weights_pair": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ymx_pack_weights_pair": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ymx_pack_weights_dgrad_s2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "ymx_conv2d_dgrad_s2": (_i, [_vp, _vp, _vp] + [_i] * 7 + [_vp]),
     "ymx_conv2d_fused": (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
     "ymx_conv2d_fused_z": (_i, [_vp] * 7 + [_i] * 9 + [_vp]),
     "ymx_conv2d_fused_ex": (_i, [_vp] * 6 + [_i] * 14 + [_vp]),

@@ -80,15 +80,18 @@ int reserve_lds(LdsReserve &st, const void *kern, int bytes, const char *what) {
 static int conv_impl(const void *x, const void *w, const void *scale, const void *shift,
                      const void *residual, void *y, int B, int H, int W, int Cin, int Cout, int k,
                      int stride, int act, int dtype, int x_dtype, int out_dtype, int x_ld, int res_ld,
-                     int y_ld, hipStream_t s, int op_min_tiles = 0, const char **label = nullptr, void *z = nullptr) {
+                     int y_ld, hipStream_t s, int op_min_tiles = 0, const char **label = nullptr, void *z = nullptr,
+                     const int *d2s = nullptr) {
     // label != nullptr: validate and select only; *label names the kernel family, nothing is launched
     // z != nullptr: the value before the activation is stored too (bf16, dense); kernels without
     // that second output run as two launches, convolution into z and then y = act(z) + residual
+    // d2s = {H', W', C}: a 2x2 window (taps at +0 / +1, zeros beyond the bottom / right edge) whose Cout = 4 C
+    // outputs per pixel are scattered depth-to-space into y [B, H', W', C]
     if (!x || !w || !y) return fail(YMX_EARG, "conv2d: null x, w or y");
     if (op_min_tiles < 0) return fail(YMX_EARG, "conv2d: negative min_tiles");
     const long long min_tiles = op_min_tiles > 0 ? op_min_tiles : dma_min_tiles();
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(YMX_EARG, "conv2d: non-positive size");
-    if (k < 1 || k > 5 || (k & 1) == 0) return fail(YMX_EUNSUPPORTED, "conv2d: kernel size %d (odd, <= 5)", k);
+    if (k < 1 || k > 5 || ((k & 1) == 0 && !(d2s && k == 2))) return fail(YMX_EUNSUPPORTED, "conv2d: kernel size %d (odd, <= 5)", k);
     if (stride != 1 && stride != 2) return fail(YMX_EUNSUPPORTED, "conv2d: stride %d (1 or 2)", stride);
     if (act != YMX_ACT_NONE && act != YMX_ACT_LEAKY && act != YMX_ACT_MISH)
         return fail(YMX_EARG, "conv2d: activation code %d", act);
@@ -99,7 +102,15 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
     a.scale = (const float *)scale; a.shift = (const float *)shift;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.k = k; a.stride = stride;
-    if (stride == 1) {
+    if (d2s) {
+        if (stride != 1 || act != YMX_ACT_NONE || residual || dtype != YMX_BF16 || out_dtype != YMX_BF16 || y_ld > 0 || z)
+            return fail(YMX_EARG, "conv2d: the depth-to-space form is bf16, stride 1, linear, without shortcut");
+        if (d2s[2] <= 0 || d2s[2] % 8 || Cout != 4 * d2s[2] || d2s[0] < 2 * H || d2s[0] > 2 * H + 1 || d2s[1] < 2 * W || d2s[1] > 2 * W + 1)
+            return fail(YMX_EARG, "conv2d: depth-to-space output [%d,%d,%d] does not match %d x %d x %d", d2s[0], d2s[1], d2s[2], H, W, Cout);
+        a.pad = 0; a.OH = H; a.OW = W;
+        a.d2s_H = d2s[0]; a.d2s_W = d2s[1]; a.d2s_c = d2s[2];
+        set_fastdiv((unsigned)a.d2s_c, a.d2s_m, a.d2s_s);
+    } else if (stride == 1) {
         a.pad = (k - 1) / 2; a.OH = H; a.OW = W;                   // SAME
     } else {
         a.pad = 1;                                                 // top/left only, then VALID
@@ -264,13 +275,28 @@ int ymx_pack_weights_dgrad(const float *w_hwio, void *w_packed, int k, int Cin, 
     return launch_pack_weights(w_hwio, w_packed, k, dz_channels, Cin, dtype, (hipStream_t)stream, Cout);
 }
 
-int ymx_pack_weights_pair(const float *w_hwio, void *w_fwd, void *w_dgrad, int k, int Cin, int Cout, int dz_channels, int dtype,
-                          void *stream) {
+int ymx_pack_weights_pair(const float *w_hwio, void *w_fwd, void *w_dgrad, int k, int Cin, int Cout, int dz_channels, int stride,
+                          int dtype, void *stream) {
     if (!w_hwio || !w_fwd || !w_dgrad) return fail(YMX_EARG, "pack_weights_pair: null pointer");
     if (k <= 0 || Cin <= 0 || Cout <= 0) return fail(YMX_EARG, "pack_weights_pair: non-positive size");
     if (dz_channels < Cout) return fail(YMX_EARG, "pack_weights_pair: dz_channels %d below Cout %d", dz_channels, Cout);
     if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "pack_weights_pair: dtype %d", dtype);
-    return launch_pack_weights_pair(w_hwio, w_fwd, w_dgrad, k, Cin, Cout, dz_channels, dtype, (hipStream_t)stream);
+    if (stride != 1 && !(stride == 2 && k == 3 && dtype == YMX_BF16)) return fail(YMX_EARG, "pack_weights_pair: stride %d (1, or 2 for 3x3 bf16)", stride);
+    return launch_pack_weights_pair(w_hwio, w_fwd, w_dgrad, k, Cin, Cout, dz_channels, stride, dtype, (hipStream_t)stream);
+}
+
+int ymx_pack_weights_dgrad_s2(const float *w_hwio, void *w_packed, int Cin, int Cout, int dz_channels, int dtype, void *stream) {
+    if (!w_hwio || !w_packed) return fail(YMX_EARG, "pack_weights_dgrad_s2: null pointer");
+    if (Cin <= 0 || Cin % 8 || Cout <= 0 || dz_channels < Cout) return fail(YMX_EARG, "pack_weights_dgrad_s2: Cin %d (a multiple of 8), Cout %d, dz_channels %d", Cin, Cout, dz_channels);
+    if (dtype != YMX_BF16) return fail(YMX_EARG, "pack_weights_dgrad_s2: dtype %d", dtype);
+    return launch_pack_weights_dgrad_s2(w_hwio, w_packed, Cin, Cout, dz_channels, dtype, (hipStream_t)stream);
+}
+
+int ymx_conv2d_dgrad_s2(const void *dz, const void *w_packed, void *dx, int B, int OH, int OW, int dz_channels, int Cin, int H, int W,
+                        void *stream) {
+    const int d2s[3] = {H, W, Cin};
+    return conv_impl(dz, w_packed, nullptr, nullptr, nullptr, dx, B, OH, OW, dz_channels, 4 * Cin, 2, 1, YMX_ACT_NONE, YMX_BF16, YMX_BF16,
+                     YMX_BF16, 0, 0, 0, (hipStream_t)stream, 0, nullptr, nullptr, d2s);
 }
 
 int ymx_conv2d_fused(const void *x, const void *w, const void *scale, const void *shift, const void *residual,

@@ -148,6 +148,11 @@ struct ConvArgs {
     // MFMA kernel walks K in this order, so all of them add the same terms in the same
     // order; the block-major order lets a kernel keep one block's input pixels in LDS and
     // reuse them for all taps.
+    // Depth-to-space output (d2s_c != 0; the input gradient of a stride-2 layer): the Cout = 4 * d2s_c
+    // channels of output pixel (b, oh, ow) are the d2s_c channels of the four pixels
+    // (2 oh + ph, 2 ow + pw), block q = 2 ph + pw, of y [B, d2s_H, d2s_W, d2s_c]
+    int d2s_c, d2s_H, d2s_W;
+    unsigned d2s_m, d2s_s;       // fastdiv constants of d2s_c
     int CB, kb;                  // channel block, k*k*CB
     unsigned kb_m, kb_s;         // fastdiv constants: K index / kb, (K index % kb) / CB, tap / k
     unsigned cb_m, cb_s;
@@ -199,6 +204,15 @@ __device__ __forceinline__ void pixel_geometry(const ConvArgs &a, int p, int &of
     }
 }
 
+// Element offset in y of channels co.. (a run that does not cross a multiple of d2s_c) of output pixel p.
+__device__ __forceinline__ size_t conv_out_offset(const ConvArgs &a, int p, int co) {
+    if (a.d2s_c == 0) return (size_t)p * a.y_ld + co;
+    const int b = fastdiv(p, a.ohw_m, a.ohw_s), rem = p - b * (a.OH * a.OW);
+    const int oh = fastdiv(rem, a.ow_m, a.ow_s), ow = rem - oh * a.OW;
+    const int q = fastdiv(co, a.d2s_m, a.d2s_s), ci = co - q * a.d2s_c;
+    return (((size_t)(b * a.d2s_H + 2 * oh + (q >> 1)) * a.d2s_W) + 2 * ow + (q & 1)) * a.d2s_c + ci;
+}
+
 // Packed weight geometry, shared by pack and conv.
 static inline bool conv_uses_mfma(int Cin, int dtype) {
     return dtype == YMX_BF16 ? (Cin % 8 == 0) : (Cin % 4 == 0);
@@ -222,8 +236,9 @@ bool conv_first_rows_eligible(const ConvArgs &a);
 int launch_conv_direct(const ConvArgs &a, hipStream_t s);
 int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype,
                         hipStream_t s, int src_cout = 0);
-int launch_pack_weights_pair(const float *w_hwio, void *w_fwd, void *w_bwd, int k, int Cin, int Cout, int dz_channels, int dtype,
-                             hipStream_t s);
+int launch_pack_weights_pair(const float *w_hwio, void *w_fwd, void *w_bwd, int k, int Cin, int Cout, int dz_channels, int stride,
+                             int dtype, hipStream_t s);
+int launch_pack_weights_dgrad_s2(const float *w_hwio, void *w_packed, int Cin, int Cout, int dz_channels, int dtype, hipStream_t s);
 int launch_upsample2x_concat(const void *skip, const void *x, void *y, int B, int H, int W, int C1,
                              int C2, int dtype, hipStream_t s);
 int launch_affine_act(const void *x, const float *scale, const float *shift, void *y, long long n, int C, int act,

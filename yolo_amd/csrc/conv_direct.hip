@@ -338,12 +338,25 @@ int launch_conv_direct(const ConvArgs &a, hipStream_t s) {
 // zeros where Cin pads src_cout).
 struct PackGeom {
     int K, Cin, Cout, Kw, rows, CB, kb, src_cout, ntaps;
+    int s2_c;       // != 0: the 2x2 depth-to-space form of a stride-2 layer's input gradient; its input channels
 };
 __device__ __forceinline__ float pack_value(const float *__restrict__ w, const PackGeom &g, size_t i) {
     const int co = (int)(i / g.Kw), kk = (int)(i - (size_t)co * g.Kw);
     // packed column kk = blk*kb + tap*CB + c  <-  HWIO row tap*Cin + blk*CB + c
     const int blk = kk / g.kb, rem = kk - blk * g.kb, tap = rem / g.CB, c = rem - tap * g.CB;
     float v = 0.0f;
+    if (g.s2_c) {
+        // row co = (q, ci): output parity q = 2 ph + pw and input channel ci of the forward layer; column = (tap
+        // (dr, dc) of the 2x2 window over dz, dz channel cz).  Input row 2 oh' + ph meets output row oh' + dr
+        // through kernel row r: ph 0: (dr 0, r 1); ph 1: (dr 0, r 2), (dr 1, r 0); columns likewise.
+        if (co < g.Cout && kk < g.K) {
+            const int q = co / g.s2_c, ci = co - q * g.s2_c, cz = blk * g.CB + c;
+            const int dr = tap >> 1, dc = tap & 1, ph = q >> 1, pw = q & 1;
+            const int r = ph ? (dr ? 0 : 2) : (dr ? -1 : 1), s = pw ? (dc ? 0 : 2) : (dc ? -1 : 1);
+            if (r >= 0 && s >= 0 && cz < g.src_cout) v = w[((size_t)(r * 3 + s) * g.s2_c + ci) * g.src_cout + cz];
+        }
+        return v;
+    }
     if (co < g.Cout && kk < g.K) {
         const int ci = blk * g.CB + c;
         if (g.src_cout == 0) v = w[(size_t)(tap * g.Cin + ci) * g.Cout + co];
@@ -382,7 +395,14 @@ copy_weights_kernel(const float *__restrict__ w, float *__restrict__ out, size_t
 static PackGeom pack_geom(int k, int Cin, int Cout, int src_cout) {
     PackGeom g;
     g.K = k * k * Cin; g.Cin = Cin; g.Cout = Cout; g.Kw = packed_kw(k, Cin); g.rows = packed_rows(Cout);
-    g.CB = conv_channel_block(Cin); g.kb = k * k * g.CB; g.src_cout = src_cout; g.ntaps = k * k;
+    g.CB = conv_channel_block(Cin); g.kb = k * k * g.CB; g.src_cout = src_cout; g.ntaps = k * k; g.s2_c = 0;
+    return g;
+}
+// input gradient of a 3x3 stride-2 layer (C input, Cout output channels) as a 2x2 convolution over dz
+// (dz_channels >= Cout) with 4 C depth-to-space output channels
+static PackGeom pack_geom_s2(int C, int Cout, int dz_channels) {
+    PackGeom g = pack_geom(2, dz_channels, 4 * C, Cout);
+    g.s2_c = C;
     return g;
 }
 
@@ -409,11 +429,24 @@ int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int
 
 // forward pack of a k x k x Cin x Cout kernel and the pack of its input-gradient convolution
 // (dz_channels >= Cout input channels, Cin output channels) in one launch; MFMA layouts only
-int launch_pack_weights_pair(const float *w_hwio, void *w_fwd, void *w_bwd, int k, int Cin, int Cout, int dz_channels, int dtype,
-                             hipStream_t s) {
+int launch_pack_weights_dgrad_s2(const float *w_hwio, void *w_packed, int Cin, int Cout, int dz_channels, int dtype, hipStream_t s) {
+    if (!conv_uses_mfma(dz_channels, dtype)) return fail(YMX_EUNSUPPORTED, "pack_weights_dgrad_s2: %d channels in dtype %d", dz_channels, dtype);
+    const PackGeom g = pack_geom_s2(Cin, Cout, dz_channels);
+    const size_t n = (size_t)g.rows * g.Kw;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (dtype == YMX_BF16)
+        hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, w_hwio, (bf16_t *)w_packed, g);
+    else
+        hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, s, w_hwio, (float *)w_packed, g);
+    return check_launch("pack_weights_dgrad_s2");
+}
+
+int launch_pack_weights_pair(const float *w_hwio, void *w_fwd, void *w_bwd, int k, int Cin, int Cout, int dz_channels, int stride,
+                             int dtype, hipStream_t s) {
     if (!conv_uses_mfma(Cin, dtype) || !conv_uses_mfma(dz_channels, dtype))
         return fail(YMX_EUNSUPPORTED, "pack_weights_pair: %d / %d channels in dtype %d take the direct kernel", Cin, dz_channels, dtype);
-    const PackGeom gf = pack_geom(k, Cin, Cout, 0), gb = pack_geom(k, dz_channels, Cin, Cout);
+    const PackGeom gf = pack_geom(k, Cin, Cout, 0);
+    const PackGeom gb = stride == 2 ? pack_geom_s2(Cin, Cout, dz_channels) : pack_geom(k, dz_channels, Cin, Cout);
     const size_t n = (size_t)gf.rows * gf.Kw + (size_t)gb.rows * gb.Kw;
     const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     if (dtype == YMX_BF16)

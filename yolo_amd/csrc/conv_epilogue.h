@@ -40,8 +40,12 @@ __device__ __forceinline__ uint32_t epi_pack2(f32x2_t v) {
 // value before the activation as a second bf16 output (ConvArgs::z), the form a training
 // step's forward pass takes.  A kernel instantiated for the tag contains only that epilogue.
 struct bf16_zout_t { bf16_t v; };
-template <typename T> struct epi_out { typedef T type; static constexpr bool zout = false; };
-template <> struct epi_out<bf16_zout_t> { typedef bf16_t type; static constexpr bool zout = true; };
+// ... and this one = bf16 outputs scattered depth-to-space (ConvArgs::d2s_c), the form the input
+// gradient of a stride-2 layer takes.
+struct bf16_d2s_t { bf16_t v; };
+template <typename T> struct epi_out { typedef T type; static constexpr bool zout = false, d2s = false; };
+template <> struct epi_out<bf16_zout_t> { typedef bf16_t type; static constexpr bool zout = true, d2s = false; };
+template <> struct epi_out<bf16_d2s_t> { typedef bf16_t type; static constexpr bool zout = false, d2s = true; };
 
 // HQMAX = channels transposed at a time: 64 (128-byte output runs, 16 KB image per wave) or 32
 // (64-byte runs, 8 KB per wave: for kernels that trade run length for workgroups per CU).
@@ -90,7 +94,7 @@ __device__ __forceinline__ void epi_run(const ConvArgs &a, f32x4_t (&acc)[NI][NJ
                                         int lane, epi_u32x4_t (&rpre)[EpiGeom<NI, HQMAX, 16 * NJ>::NH][EpiGeom<NI, HQMAX, 16 * NJ>::NPASS]) {
     typedef EpiGeom<NI, HQMAX, 16 * NJ> G;
     typedef typename epi_out<OTAG>::type OT;
-    constexpr bool ZKERNEL = epi_out<OTAG>::zout;
+    constexpr bool ZKERNEL = epi_out<OTAG>::zout, D2S = epi_out<OTAG>::d2s;
     static_assert(NJ == 4 || NJ == 3, "wave tiles are 64 or 48 pixels wide");
     constexpr int HQ = G::HQ, NH = G::NH, SLOTS = G::SLOTS, LPP = G::LPP, PPI = G::PPI, NPASS = G::NPASS;
     OT *__restrict__ y = (OT *)a.y;
@@ -172,7 +176,9 @@ __device__ __forceinline__ void epi_run(const ConvArgs &a, f32x4_t (&acc)[NI][NJ
                     }
                 }
                 if (p < a.P && co < a.Cout) {
-                    OT *yp = y + (size_t)p * a.y_ld + co;
+                    OT *yp;
+                    if constexpr (D2S) yp = y + conv_out_offset(a, p, co);
+                    else yp = y + (size_t)p * a.y_ld + co;
                     if constexpr (ZOUT) store_stream16((bf16_t *)a.z + (size_t)p * a.Cout + co, zq[0], zq[1], zq[2], zq[3]);
                     if constexpr (sizeof(OT) == 2) {
                         store_stream16(yp, epi_pack2(o[0]), epi_pack2(o[1]), epi_pack2(o[2]), epi_pack2(o[3]));
@@ -196,7 +202,9 @@ __device__ __forceinline__ void epi_run(const ConvArgs &a, f32x4_t (&acc)[NI][NJ
         else fast(std::integral_constant<int, YMX_ACT_LEAKY>{}, res_tag, std::true_type{});
     };
 
-    if constexpr (ZKERNEL) {                     // the launcher guarantees epi_vec_ok, a.z and Mish / leaky
+    if constexpr (D2S) {                         // the launcher guarantees epi_vec_ok, no shortcut, no activation
+        fast(std::integral_constant<int, YMX_ACT_NONE>{}, std::false_type{}, std::false_type{});
+    } else if constexpr (ZKERNEL) {                     // the launcher guarantees epi_vec_ok, a.z and Mish / leaky
         if (res == nullptr) fast_z(std::false_type{});
         else fast_z(std::true_type{});
     } else if (epi_vec_ok(a) && res == nullptr) {

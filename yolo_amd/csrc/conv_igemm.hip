@@ -199,7 +199,7 @@ conv_igemm_kernel(const ConvArgs a, const int ntile_q, const int nk) {
                         v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
                     }
                 }
-                OT *yp = y + (size_t)p * a.y_ld + co;
+                OT *yp = y + conv_out_offset(a, p, co);
                 if constexpr (sizeof(OT) == 2) {
                     *(uint2 *)yp = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
                 } else {
@@ -211,7 +211,7 @@ conv_igemm_kernel(const ConvArgs a, const int ntile_q, const int nk) {
                     if (co + r < a.Cout) {
                         float o = v[r];
                         if (res) o += elem<T>::load(res + (size_t)p * a.res_ld + co + r);
-                        elem<OT>::store(y + (size_t)p * a.y_ld + co + r, o);
+                        elem<OT>::store(y + conv_out_offset(a, p, co + r), o);
                     }
                 }
             }

@@ -178,6 +178,7 @@ static int launch_dma_cfg(const ConvArgs &a, hipStream_t s) {
 int launch_conv_igemm_dma(const ConvArgs &a, hipStream_t s) {
     if (a.dtype != YMX_BF16) return fail(YMX_EUNSUPPORTED, "conv_igemm_dma: bf16 operands only");
     if (a.z) return launch_dma_cfg<bf16_zout_t, 256>(a, s);
+    if (a.d2s_c) return launch_dma_cfg<bf16_d2s_t, 256>(a, s);
     if (a.out_dtype == YMX_BF16) return launch_dma_cfg<bf16_t, 256>(a, s);
     return launch_dma_cfg<float, 256>(a, s);
 }

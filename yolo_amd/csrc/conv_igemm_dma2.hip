@@ -253,6 +253,7 @@ static int launch_dma2_shape(const ConvArgs &a, hipStream_t s) {
 int launch_conv_igemm_dma2(const ConvArgs &a, hipStream_t s) {
     if (a.dtype != YMX_BF16) return fail(YMX_EUNSUPPORTED, "conv_igemm_dma2: bf16 operands only");
     if (a.z) return launch_dma2_shape<bf16_zout_t>(a, s);
+    if (a.d2s_c) return launch_dma2_shape<bf16_d2s_t>(a, s);
     if (a.out_dtype == YMX_BF16) return launch_dma2_shape<bf16_t>(a, s);
     return launch_dma2_shape<float>(a, s);
 }

@@ -80,7 +80,7 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
             for (int i = 0; i < 2; ++i) lds_dma16(wrsrc, sbase + (unsigned)(i * 1024), kt < nk ? base + woff[i] : OOB);
         } else {
             if constexpr (POS == 1) {       // K index -> (tap, channel) -> (row, col), once per tile
-                if (a.CB == 64 && a.k <= 3) {
+                if (a.CB == 64 && (a.k == 1 || a.k == 3)) {
                     // whole 64-channel blocks: a K tile is one (block, tap), the same for every lane,
                     // so the decode is scalar arithmetic
                     const int kk = a.k * a.k;
@@ -293,6 +293,7 @@ static int launch_dma4_cfg(const ConvArgs &a, hipStream_t s) {
 int launch_conv_igemm_dma4(const ConvArgs &a, hipStream_t s) {
     if (a.dtype != YMX_BF16) return fail(YMX_EUNSUPPORTED, "conv_igemm_dma4: bf16 operands only");
     if (a.z) return launch_dma4_cfg<bf16_zout_t>(a, s);
+    if (a.d2s_c) return launch_dma4_cfg<bf16_d2s_t>(a, s);
     if (a.out_dtype == YMX_BF16) return launch_dma4_cfg<bf16_t>(a, s);
     return launch_dma4_cfg<float>(a, s);
 }

@@ -15,14 +15,18 @@ namespace ymx {
 
 // ---- activation: forward with z kept, and derivative ----------------------------------------
 __device__ __forceinline__ float mish_grad_f(float z) {
-    // d/dz [z * tanh(softplus(z))] = t + z * s * (1 - t^2),  t = tanh(softplus(z)) = n / (n + 2),
-    // n = e (e + 2), e = exp(z), s = sigmoid(z) = e / (1 + e); -> 1 for large z, -> 0 for very negative z
-    if (z > 20.0f) return 1.0f;
-    const float e = __expf(z);
-    const float n = e * (e + 2.0f);
-    const float t = n / (n + 2.0f);
-    const float s = e / (1.0f + e);
-    return t + z * s * (1.0f - t * t);
+    // d/dz [z * tanh(softplus(z))] with e = exp(z):
+    //   tanh(softplus(z)) = n / d,  n = e (e + 2),  d = n + 2
+    //   derivative = e * w / d^2,   w = 4 (z + 1) + e (4 z + 6 + e (4 + e))
+    // one exponential and one reciprocal (1 ulp each), the rest multiply-adds; -> 1 for large z
+    // (taken as 1 beyond 20, where e^4z would leave the fp32 range), -> 0 for very negative z
+#pragma clang fp contract(fast)
+    const float zc = fminf(z, 20.0f);
+    const float e = __builtin_amdgcn_exp2f(zc * 1.44269504088896f);
+    const float w = 4.0f * zc + 4.0f + e * (4.0f * zc + 6.0f + e * (4.0f + e));
+    const float d = e * (e + 2.0f) + 2.0f;
+    const float g = e * w * __builtin_amdgcn_rcpf(d * d);
+    return z > 20.0f ? 1.0f : g;
 }
 
 template <typename T> __device__ __forceinline__ float ld_f(const T *p, size_t i);

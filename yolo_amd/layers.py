@@ -238,7 +238,8 @@ class YOLOConv(nn.Module):
         step: both layouts come out of one launch (ymx_pack_weights_pair) and are kept until
         the kernel or the bias changes, i.e. for the forward and the backward pass of a step.
         Layers whose input channels do not take the MFMA kernels (the first: 3) have no
-        input-gradient pack."""
+        input-gradient pack; stride-2 layers get the 2x2 depth-to-space form
+        (ymx_conv2d_dgrad_s2)."""
         if self.batch_normalization:
             raise ValueError("YOLOConv.packed_training: batch normalisation layers are not trained")
         dev = self.kernel.device
@@ -256,9 +257,13 @@ class YOLOConv(nn.Module):
             code = _lib.dtype_code(dtype)
             coutp = -(-cout // 8) * 8
             wp = torch.empty(L.ymx_packed_weight_bytes(k, cin, cout, code), dtype=torch.uint8, device=dev)
-            wdp = torch.empty(L.ymx_packed_weight_bytes(k, coutp, cin, code), dtype=torch.uint8, device=dev)
+            stride = 2 if self.downsample else 1
+            if stride == 2 and k != 3:
+                raise ValueError("YOLOConv.packed_training: stride-2 convolutions are 3x3")
+            nb = L.ymx_packed_weight_bytes(2, coutp, 4 * cin, code) if stride == 2 else L.ymx_packed_weight_bytes(k, coutp, cin, code)
+            wdp = torch.empty(nb, dtype=torch.uint8, device=dev)
             src = self.kernel.detach().float().contiguous()
-            _lib.launch("ymx_pack_weights_pair", wp, _lib.ptr(src), _lib.ptr(wp), _lib.ptr(wdp), k, cin, cout, coutp, code)
+            _lib.launch("ymx_pack_weights_pair", wp, _lib.ptr(src), _lib.ptr(wp), _lib.ptr(wdp), k, cin, cout, coutp, stride, code)
             entry = (wp, self.bias.detach().float().contiguous(), wdp, src)
         self._packed["train"] = (key, entry)
         return entry

@@ -11,7 +11,8 @@ libymx:
   backward  dz = dy * act'(z)             ymx_act_backward
             dbias = sum_p dz              ymx_bias_grad
             dkernel = x (*) dz            ymx_conv_wgrad (HWIO fp32, the kernel's own layout)
-            dx = conv(dz, kernel flipped and transposed)      the forward kernels again
+            dx = conv(dz, kernel flipped and transposed)      the forward kernels again (stride 2:
+                                                              a 2x2 window, depth-to-space outputs)
             dshortcut = dy
 
 Use::
@@ -266,18 +267,20 @@ class _ConvBlock(torch.autograd.Function):
             wdp = layer.packed_training(cdt)[2]                   # packed with the forward kernel, in the same launch
             if wdp is None:
                 raise ValueError("yolo_amd.training: no input gradient for a layer of %d input channels" % cin)
-            src = dzp
-            if stride == 2:
-                if k != 3:
-                    raise ValueError("yolo_amd.training: stride-2 convolutions are 3x3")
-                src = torch.zeros((b, h, w, coutp), device=x.device, dtype=cdt)       # dz on the even rows / columns
-                src[:, 0:2 * oh:2, 0:2 * ow:2] = dzp
             res = None
             if ctx.link is not None and not ctx.has_shortcut:
                 res, ctx.link.pending = ctx.link.pending, None        # the shortcut's gradient, left by the block after this one
                 if res is not None and (res.dtype != cdt or tuple(res.shape) != (b, h, w, cin)):
                     raise RuntimeError("yolo_amd.training: shortcut gradient does not match the block's input")
-            dx = _conv(src, wdp, None, coutp, cin, k, 1, cdt, cdt, residual=res)
+            if stride == 2:
+                # a 2x2 convolution over dz whose 4 * cin outputs per pixel land depth-to-space in dx
+                if res is not None:
+                    raise RuntimeError("yolo_amd.training: a stride-2 block does not start a ResidialBlock")
+                even = h % 2 == 0 and w % 2 == 0             # the last row / column of an odd-sized input has no gradient
+                dx = (torch.empty if even else torch.zeros)((b, h, w, cin), device=x.device, dtype=cdt)
+                _lib.launch("ymx_conv2d_dgrad_s2", dzp, _lib.ptr(dzp), _lib.ptr(wdp), _lib.ptr(dx), b, oh, ow, coutp, cin, h, w)
+            else:
+                dx = _conv(dzp, wdp, None, coutp, cin, k, 1, cdt, cdt, residual=res)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
         if ctx.needs_input_grad[1]:
