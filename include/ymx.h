@@ -319,6 +319,38 @@ int ymx_yolo_loss_grad(const float *conv, int conv_ld, const float *label, long 
  * other channel slice of dy as it is).  n / n_pix count elements / pixels; ld strides are in
  * elements, 0 = dense. */
 int ymx_act_apply(const void *z, const void *residual, void *y, long long n, int act, int dtype, void *stream);
+/* The SPP block (/root/reference/backbones.py:254-259) for a training step: the outputs of
+ * ymx_spp_concat plus argmax [B,H,W,3,C] bytes, the row-major position inside its k x k window
+ * (k = 13, 9, 5) of the first maximum each pooled value was taken from; the backward call
+ * gives dx [B,H,W,C] from dy [B,H,W,4C]: the pass-through slice plus every pooled gradient at
+ * its argmax (gathered per input element, fixed summation order). */
+int ymx_spp_concat_train(const void *x, void *y, unsigned char *argmax, int B, int H, int W, int C, int dtype,
+                         void *stream);
+int ymx_spp_concat_backward(const void *dy, const unsigned char *argmax, void *dx, int B, int H, int W, int C,
+                            int dtype, void *stream);
+/* Batch normalisation in training mode (/root/reference/layers.py:4-15 under model.fit: Keras
+ * normalises with the statistics of the batch and keeps moving averages for inference).  Dense
+ * [n_pix, C] rows, bf16 or fp32; every sums vector holds 2 * C floats; workspaces of
+ * ymx_bn_workspace_bytes(n_pix, C); sums are taken in two ordered stages (reproducible).
+ *   ymx_bn_stats          sums = (sum_p u, sum_p u^2): the caller forms mean, the biased variance,
+ *                         scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+ *   ymx_bn_act_forward    y = act(u * scale + shift) + residual (residual may be NULL)
+ *   ymx_bn_act_backward   dz = dy * act'(u * scale + shift) stored in the tensors' type, and
+ *                         sums = (sum_p dz, sum_p dz * u), from which dbeta = sum dz,
+ *                         dgamma = s (sum dz u - mean sum dz), s = 1 / sqrt(var + eps)
+ *   ymx_bn_backward_apply du = a[c] * dz + b[c] * u + c[c]; with N = n_pix the gradient of the
+ *                         normalisation's input is a = gamma s, b = -gamma s^2 dgamma / N,
+ *                         c = gamma s (s mean dgamma - dbeta) / N */
+size_t ymx_bn_workspace_bytes(long long n_pix, int C);
+int ymx_bn_stats(const void *u, long long n_pix, int C, int dtype, float *sums, void *workspace, size_t ws_bytes,
+                 void *stream);
+int ymx_bn_act_forward(const void *u, const float *scale, const float *shift, const void *residual, void *y,
+                       long long n_pix, int C, int act, int dtype, void *stream);
+int ymx_bn_act_backward(const void *u, const void *dy, const float *scale, const float *shift, void *dz,
+                        long long n_pix, int C, int act, int dtype, float *sums, void *workspace, size_t ws_bytes,
+                        void *stream);
+int ymx_bn_backward_apply(const void *dz, const void *u, const float *a, const float *b, const float *c, void *du,
+                          long long n_pix, int C, int dtype, void *stream);
 int ymx_act_backward(const void *z, const void *dy, void *dz, long long n, int act, int dtype, void *stream);
 /* ymx_act_backward and ymx_bias_grad in one pass over dense [n_pix, C] rows (bf16, act 1 or 2,
  * C / 8 a power of two up to 256; ..._workspace_bytes returns 0 for anything else). */

@@ -47,7 +47,27 @@ def activation(x, act):
     raise ValueError("Activation should either be a function or one of \"leaky\" or \"mish\".")
 
 
-def yolo_conv(x, p, downsample=False, act="mish"):
+BN_MOMENTUM = 0.99      # Keras BatchNormalization default, used unchanged at layers.py:4
+
+
+def batch_norm_train(y_nchw, p, update=None):
+    """BatchNormalization.call with training=True and a trainable layer (layers.py:11-15 hands
+    over to Keras): normalise with the batch's own mean and biased variance over N, H, W, then
+    gamma / beta.  `update`, if a dict, receives the moving statistics Keras would keep
+    afterwards (momentum 0.99; the fused kernel Keras takes for NHWC inputs feeds the moving
+    variance with the unbiased estimate, n / (n - 1) times the biased one)."""
+    mean = y_nchw.mean(dim=(0, 2, 3))
+    var = y_nchw.var(dim=(0, 2, 3), unbiased=False)
+    if update is not None:
+        n = y_nchw.numel() // y_nchw.shape[1]
+        with torch.no_grad():
+            update["mean"] = p["mean"] * BN_MOMENTUM + mean.detach() * (1 - BN_MOMENTUM)
+            update["var"] = p["var"] * BN_MOMENTUM + var.detach() * (n / max(n - 1, 1)) * (1 - BN_MOMENTUM)
+    xhat = (y_nchw - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + BN_EPS)
+    return xhat * p["gamma"].view(1, -1, 1, 1) + p["beta"].view(1, -1, 1, 1)
+
+
+def yolo_conv(x, p, downsample=False, act="mish", bn_training=False, bn_update=None, bn_round=None):
     """One YOLOConv block on an NHWC tensor; layers.py:46-81.
 
     p: dict with 'kernel' [kh,kw,Cin,Cout] and either 'bias' [Cout] or the
@@ -65,7 +85,11 @@ def yolo_conv(x, p, downsample=False, act="mish"):
     else:
         # TF SAME at stride 1 with an odd kernel pads (k-1)/2 on every side.
         y = F.conv2d(xn, w, p.get("bias"), stride=1, padding=((kh - 1) // 2, (kw - 1) // 2))
-    if "gamma" in p:
+    if "gamma" in p and bn_round is not None:
+        y = bn_round(y)              # what a reduced-precision path stores between the convolution and the normalisation
+    if "gamma" in p and bn_training:
+        y = batch_norm_train(y, p, bn_update)
+    elif "gamma" in p:
         scale = p["gamma"] / torch.sqrt(p["var"] + BN_EPS)
         shift = p["beta"] - p["mean"] * scale
         y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)

@@ -35,6 +35,13 @@ SIGNATURES = {
     "ymx_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "ymx_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ymx_pack_weights_dgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ymx_spp_concat_train": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ymx_spp_concat_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ymx_bn_workspace_bytes": (_sz, [_ll, _i]),
+    "ymx_bn_stats": (_i, [_vp, _ll, _i, _i, _vp, _vp, _sz, _vp]),
+    "ymx_bn_act_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
+    "ymx_bn_act_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "ymx_bn_backward_apply": (_i, [_vp] * 6 + [_ll, _i, _i, _vp]),
     "ymx_pack_weights_pair": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ymx_pack_weights_dgrad_s2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ymx_conv2d_dgrad_s2": (_i, [_vp, _vp, _vp] + [_i] * 7 + [_vp]),

@@ -10,6 +10,7 @@ class here is the repaired definition (ResidialBlock(in, f1, f2) -> ResidialBloc
 import torch
 from torch import nn
 
+from . import training as _training
 from .layers import YOLOConv, ResidialBlock, spp_concat
 
 
@@ -177,6 +178,9 @@ class CSPDarknet53(nn.Module):
         probe = flat_convs(main)[-1]
         dt = probe.compute_dtype or x_main.dtype
         b, h, w = x_main.shape[0], x_main.shape[1], x_main.shape[2]
+        if _training.enabled():
+            # recorded for back-propagation: the branches' gradients are the two channel slices of the concat's
+            return torch.cat([self._run(main, x_main), self._run(skip, x_skip)], dim=-1)
         cat = torch.empty((b, h, w, c1 + c2), device=x_main.device, dtype=dt)
         self._run(main, x_main, out=cat[..., :c1])
         self._run(skip, x_skip, out=cat[..., c1:])

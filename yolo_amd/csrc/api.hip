@@ -509,6 +509,20 @@ int ymx_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dtype
     return launch_spp_concat(x, y, B, H, W, C, dtype, (hipStream_t)stream);
 }
 
+int ymx_spp_concat_train(const void *x, void *y, unsigned char *argmax, int B, int H, int W, int C, int dtype, void *stream) {
+    if (!x || !y || !argmax) return fail(YMX_EARG, "spp_concat_train: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(YMX_EARG, "spp_concat_train: non-positive size");
+    if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "spp_concat_train: dtype %d", dtype);
+    return launch_spp_train(x, y, argmax, B, H, W, C, dtype, (hipStream_t)stream);
+}
+
+int ymx_spp_concat_backward(const void *dy, const unsigned char *argmax, void *dx, int B, int H, int W, int C, int dtype, void *stream) {
+    if (!dy || !dx || !argmax) return fail(YMX_EARG, "spp_concat_backward: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(YMX_EARG, "spp_concat_backward: non-positive size");
+    if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "spp_concat_backward: dtype %d", dtype);
+    return launch_spp_bwd(dy, argmax, dx, B, H, W, C, dtype, (hipStream_t)stream);
+}
+
 int ymx_act_apply(const void *z, const void *residual, void *y, long long n, int act, int dtype, void *stream) {
     if (!z || !y) return fail(YMX_EARG, "act_apply: null pointer");
     if (n <= 0) return fail(YMX_EARG, "act_apply: non-positive size");
@@ -686,6 +700,44 @@ int ymx_affine_act(const void *x, const float *scale, const float *shift, void *
     if (act != YMX_ACT_NONE && act != YMX_ACT_LEAKY && act != YMX_ACT_MISH) return fail(YMX_EARG, "affine_act: activation code %d", act);
     if (n_pix == 0) return YMX_OK;
     return launch_affine_act(x, scale, shift, y, n_pix * C, C, act, dtype, (hipStream_t)stream);
+}
+
+static int bn_args_ok(const char *what, long long n_pix, int C, int dtype) {
+    if (n_pix <= 0 || C <= 0) return fail(YMX_EARG, "%s: bad size", what);
+    if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "%s: dtype %d", what, dtype);
+    return YMX_OK;
+}
+size_t ymx_bn_workspace_bytes(long long n_pix, int C) { return (n_pix > 0 && C > 0) ? bn_workspace_bytes(n_pix, C) : 0; }
+
+int ymx_bn_stats(const void *u, long long n_pix, int C, int dtype, float *sums, void *workspace, size_t ws_bytes, void *stream) {
+    if (!u || !sums || !workspace) return fail(YMX_EARG, "bn_stats: null pointer");
+    if (const int rc = bn_args_ok("bn_stats", n_pix, C, dtype)) return rc;
+    if (ws_bytes < bn_workspace_bytes(n_pix, C)) return fail(YMX_EARG, "bn_stats: workspace of %zu bytes, %zu needed", ws_bytes, bn_workspace_bytes(n_pix, C));
+    return launch_bn_reduce(u, nullptr, nullptr, nullptr, nullptr, n_pix, C, 0, dtype, sums, workspace, (hipStream_t)stream);
+}
+
+int ymx_bn_act_forward(const void *u, const float *scale, const float *shift, const void *residual, void *y, long long n_pix, int C,
+                       int act, int dtype, void *stream) {
+    if (!u || !y || !scale || !shift) return fail(YMX_EARG, "bn_act_forward: null pointer");
+    if (const int rc = bn_args_ok("bn_act_forward", n_pix, C, dtype)) return rc;
+    if (act != YMX_ACT_NONE && act != YMX_ACT_LEAKY && act != YMX_ACT_MISH) return fail(YMX_EARG, "bn_act_forward: activation code %d", act);
+    return launch_affine_act(u, scale, shift, y, n_pix * C, C, act, dtype, (hipStream_t)stream, residual);
+}
+
+int ymx_bn_act_backward(const void *u, const void *dy, const float *scale, const float *shift, void *dz, long long n_pix, int C, int act,
+                        int dtype, float *sums, void *workspace, size_t ws_bytes, void *stream) {
+    if (!u || !dy || !dz || !scale || !shift || !sums || !workspace) return fail(YMX_EARG, "bn_act_backward: null pointer");
+    if (const int rc = bn_args_ok("bn_act_backward", n_pix, C, dtype)) return rc;
+    if (act != YMX_ACT_NONE && act != YMX_ACT_LEAKY && act != YMX_ACT_MISH) return fail(YMX_EARG, "bn_act_backward: activation code %d", act);
+    if (ws_bytes < bn_workspace_bytes(n_pix, C)) return fail(YMX_EARG, "bn_act_backward: workspace of %zu bytes, %zu needed", ws_bytes, bn_workspace_bytes(n_pix, C));
+    return launch_bn_reduce(u, dy, dz, scale, shift, n_pix, C, act, dtype, sums, workspace, (hipStream_t)stream);
+}
+
+int ymx_bn_backward_apply(const void *dz, const void *u, const float *a, const float *b, const float *c, void *du, long long n_pix, int C,
+                          int dtype, void *stream) {
+    if (!dz || !u || !a || !b || !c || !du) return fail(YMX_EARG, "bn_backward_apply: null pointer");
+    if (const int rc = bn_args_ok("bn_backward_apply", n_pix, C, dtype)) return rc;
+    return launch_bn_bwd_apply(dz, u, a, b, c, du, n_pix, C, dtype, (hipStream_t)stream);
 }
 
 int ymx_bbox_iou(const float *b1, const float *b2, float *out, long long n, int giou, void *stream) {

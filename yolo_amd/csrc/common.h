@@ -242,10 +242,12 @@ int launch_pack_weights_dgrad_s2(const float *w_hwio, void *w_packed, int Cin, i
 int launch_upsample2x_concat(const void *skip, const void *x, void *y, int B, int H, int W, int C1,
                              int C2, int dtype, hipStream_t s);
 int launch_affine_act(const void *x, const float *scale, const float *shift, void *y, long long n, int C, int act,
-                      int dtype, hipStream_t s);
+                      int dtype, hipStream_t s, const void *res = nullptr);
 int launch_bbox_iou(const float *b1, const float *b2, float *out, long long n, int giou,
                     hipStream_t s);
 int launch_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dtype, hipStream_t s);
+int launch_spp_train(const void *x, void *y, unsigned char *arg, int B, int H, int W, int C, int dtype, hipStream_t s);
+int launch_spp_bwd(const void *dy, const unsigned char *arg, void *dx, int B, int H, int W, int C, int dtype, hipStream_t s);
 int launch_letterbox(const void *src, int in_u8, int B, int H, int W, void *dst, int out_bf16, int T, int literal, hipStream_t s);
 int launch_draw_boxes(unsigned char *img, int B, int H, int W, const float *boxes, const float *classes, const int *valid, int M,
                       const unsigned char *colors, int C, int thick, hipStream_t s);
@@ -255,6 +257,11 @@ bool act_bwd_bias_supported(long long P, int C, int act, int dtype);
 size_t act_bwd_bias_workspace_bytes(long long P, int C);
 int launch_act_bwd_bias(const void *z, const void *dy, void *dz, long long P, int C, int act, float *db, void *ws, hipStream_t s);
 int launch_bias_grad(const void *dz, long long P, int C, int ld, int dtype, float *db, void *ws, hipStream_t s);
+size_t bn_workspace_bytes(long long P, int C);
+int launch_bn_reduce(const void *u, const void *dy, void *dz, const float *scale, const float *shift, long long P, int C, int act,
+                     int dtype, float *sums, void *ws, hipStream_t s);
+int launch_bn_bwd_apply(const void *dz, const void *u, const float *a, const float *b, const float *c, void *du, long long P, int C,
+                        int dtype, hipStream_t s);
 size_t conv_wgrad_workspace_bytes(int k, int Cin, int Cout, long long P);
 int launch_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw, int B, int H, int W, int Cin, int Cout, int k,
                       int stride, void *ws, hipStream_t s);

@@ -118,25 +118,27 @@ int launch_bbox_iou(const float *b1, const float *b2, float *out, long long n, i
 template <typename T>
 __global__ void __launch_bounds__(256)
 affine_act_kernel(const T *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
-                  T *__restrict__ y, long long n, int C, int act) {
+                  const T *__restrict__ res, T *__restrict__ y, long long n, int C, int act) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % C);
         float v = elem<T>::load(x + i);
         v = v * (scale ? scale[c] : 1.0f) + (shift ? shift[c] : 0.0f);
-        elem<T>::store(y + i, act_f(v, act));
+        v = act_f(v, act);
+        if (res) v += elem<T>::load(res + i);                       // the shortcut of a ResidialBlock, after the activation
+        elem<T>::store(y + i, v);
     }
 }
 
 int launch_affine_act(const void *x, const float *scale, const float *shift, void *y, long long n, int C, int act,
-                      int dtype, hipStream_t s) {
+                      int dtype, hipStream_t s, const void *res) {
     const long long blocks = (n + 255) / 256;
     const int grid = (int)(blocks < 16384 ? blocks : 16384);
     if (dtype == YMX_BF16)
         hipLaunchKernelGGL((affine_act_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t *)x, scale, shift,
-                           (bf16_t *)y, n, C, act);
+                           (const bf16_t *)res, (bf16_t *)y, n, C, act);
     else
         hipLaunchKernelGGL((affine_act_kernel<float>), dim3(grid), dim3(256), 0, s, (const float *)x, scale, shift,
-                           (float *)y, n, C, act);
+                           (const float *)res, (float *)y, n, C, act);
     return check_launch("affine_act");
 }
 

@@ -4,6 +4,7 @@
 //   - the YOLO loss of one scale, forward (/root/reference/losses.py:10-46 with the decode of
 //     utils.py:107-131 fused in), without materialising the [B,S,S,3,128] IoU tensor;
 //   - label assignment for a batch (/root/reference/dataset.py:387-482).
+#include <algorithm>
 #include <cstring>
 
 #include "common.h"
@@ -103,6 +104,89 @@ int launch_spp_concat(const void *x, void *y, int B, int H, int W, int C, int dt
     }
 #undef YMX_SPP
     return check_launch("spp_concat");
+}
+
+// ---- SPP block with its derivative ----------------------------------------------------------------
+// Training form of spp_concat (backbones.py:254-259): the same outputs plus, for every pooled value,
+// where in its window it came from (row-major position inside the k x k window, the first maximum in
+// scan order), so that the backward pass hands each pooled gradient to exactly one input element:
+//   dx[p] = dy_x[p] + sum over k in {13, 9, 5}, over the outputs o whose window holds p:
+//           dy_k[o] if arg_k[o] == position of p in o's window.
+// The backward kernel gathers (one thread per input element walks the outputs around it), so no
+// atomics are needed and the sum has a fixed order.  One thread per (pixel, channel).
+template <typename T>
+__global__ void __launch_bounds__(256)
+spp_argmax_kernel(const T *__restrict__ x, T *__restrict__ y, unsigned char *__restrict__ arg, int B, int H, int W, int C) {
+    const size_t total = (size_t)B * H * W * C;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        size_t r = idx / C;
+        const int j = (int)(r % W);
+        r /= W;
+        const int i = (int)(r % H), b = (int)(r / H);
+        const size_t pix = ((size_t)b * H + i) * W + j;
+        const T *xb = x + (size_t)b * H * W * C + c;
+#pragma unroll
+        for (int pool = 0; pool < 3; ++pool) {
+            const int k = pool == 0 ? 13 : (pool == 1 ? 9 : 5), rad = k / 2;
+            float best = -INFINITY;
+            int where = 0;
+            for (int di = -rad; di <= rad; ++di) {
+                const int ii = i + di;
+                if (ii < 0 || ii >= H) continue;
+                for (int dj = -rad; dj <= rad; ++dj) {
+                    const int jj = j + dj;
+                    if (jj < 0 || jj >= W) continue;
+                    const float v = elem<T>::load(xb + ((size_t)ii * W + jj) * C);
+                    if (v > best) { best = v; where = (di + rad) * k + dj + rad; }
+                }
+            }
+            elem<T>::store(y + pix * 4 * C + pool * C + c, best);
+            arg[(pix * 3 + pool) * C + c] = (unsigned char)where;
+        }
+        elem<T>::store(y + pix * 4 * C + 3 * C + c, elem<T>::load(x + idx));
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+spp_bwd_kernel(const T *__restrict__ dy, const unsigned char *__restrict__ arg, T *__restrict__ dx, int B, int H, int W, int C) {
+    const size_t total = (size_t)B * H * W * C;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        size_t r = idx / C;
+        const int j = (int)(r % W);
+        r /= W;
+        const int i = (int)(r % H), b = (int)(r / H);
+        const size_t pix = ((size_t)b * H + i) * W + j;
+        float acc = elem<T>::load(dy + pix * 4 * C + 3 * C + c);
+#pragma unroll
+        for (int pool = 0; pool < 3; ++pool) {
+            const int k = pool == 0 ? 13 : (pool == 1 ? 9 : 5), rad = k / 2;
+            for (int oi = max(i - rad, 0); oi <= min(i + rad, H - 1); ++oi)
+                for (int oj = max(j - rad, 0); oj <= min(j + rad, W - 1); ++oj) {
+                    const size_t op = ((size_t)b * H + oi) * W + oj;
+                    const int mine = (i - oi + rad) * k + (j - oj + rad);
+                    if (arg[(op * 3 + pool) * C + c] == mine) acc += elem<T>::load(dy + op * 4 * C + pool * C + c);
+                }
+        }
+        elem<T>::store(dx + idx, acc);
+    }
+}
+
+int launch_spp_train(const void *x, void *y, unsigned char *arg, int B, int H, int W, int C, int dtype, hipStream_t s) {
+    const size_t total = (size_t)B * H * W * C;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 1 << 16);
+    if (dtype == YMX_BF16) hipLaunchKernelGGL(spp_argmax_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t *)x, (bf16_t *)y, arg, B, H, W, C);
+    else hipLaunchKernelGGL(spp_argmax_kernel<float>, dim3(grid), dim3(256), 0, s, (const float *)x, (float *)y, arg, B, H, W, C);
+    return check_launch("spp_concat_train");
+}
+int launch_spp_bwd(const void *dy, const unsigned char *arg, void *dx, int B, int H, int W, int C, int dtype, hipStream_t s) {
+    const size_t total = (size_t)B * H * W * C;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 1 << 16);
+    if (dtype == YMX_BF16) hipLaunchKernelGGL(spp_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t *)dy, arg, (bf16_t *)dx, B, H, W, C);
+    else hipLaunchKernelGGL(spp_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float *)dy, arg, (float *)dx, B, H, W, C);
+    return check_launch("spp_concat_backward");
 }
 
 // ---- YOLO loss of one scale, forward ---------------------------------------------------------

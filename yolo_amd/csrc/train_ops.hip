@@ -292,6 +292,90 @@ int launch_act_bwd_bias(const void *z, const void *dy, void *dz, long long P, in
     return check_launch("act_backward_bias_reduce");
 }
 
+
+// ---- batch normalisation in training mode -------------------------------------------------------
+// /root/reference/layers.py:4-15 under model.fit: Keras normalises with the statistics of the batch,
+//   y = gamma * (u - mean_B) / sqrt(var_B + eps) + beta   (var_B biased, over all pixels of the batch),
+// and keeps moving averages for inference.  The pieces here (dense [n_pix][C] rows, bf16 or fp32):
+//   bn_stats       sums[0][c] = sum_p u,  sums[1][c] = sum_p u^2            (forward)
+//   bn_act_bwd     dz = dy * act'(u * scale[c] + shift[c]) stored, and
+//                  sums[0][c] = sum_p dz,  sums[1][c] = sum_p dz * u        (backward, pass 1)
+//   bn_bwd_apply   du = a[c] * dz + b[c] * u + c[c]                         (backward, pass 2)
+// from which the host forms mean / variance and, with s = 1 / sqrt(var + eps), N pixels,
+//   dbeta = sum dz,  dgamma = s * (sum dz u - mean * sum dz),
+//   du = gamma s (dz - dbeta / N - xhat dgamma / N),  xhat = (u - mean) s.
+// Sums are taken in two ordered stages (slabs of rows per workgroup, then the slabs in order), so
+// results are reproducible.  One thread walks one channel of its slab; consecutive threads read
+// consecutive channels.
+template <typename T, int MODE>          // MODE 0: (u, u^2);  1: (dz, dz * u) with dz computed and stored
+__global__ void __launch_bounds__(256)
+bn_reduce_kernel(const T *__restrict__ u, const T *__restrict__ dy, T *__restrict__ dz, const float *__restrict__ scale,
+                 const float *__restrict__ shift, float *__restrict__ partial, long long P, int C, long long rows_per, int act) {
+    const long long r0 = (long long)blockIdx.x * rows_per;
+    const long long r1 = r0 + rows_per < P ? r0 + rows_per : P;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s0 = 0.0f, s1 = 0.0f;
+        const float sc = MODE == 1 ? scale[c] : 1.0f, sh = MODE == 1 ? shift[c] : 0.0f;
+        for (long long r = r0; r < r1; ++r) {
+            const size_t i = (size_t)r * C + c;
+            const float v = ld_f(u, i);
+            if (MODE == 0) {
+                s0 += v;
+                s1 += v * v;
+            } else {
+                const float z = v * sc + sh;
+                const float g = act == 2 ? mish_grad_f(z) : (act == 1 ? (z > 0.0f ? 1.0f : 0.1f) : 1.0f);
+                st_f(dz, i, ld_f(dy, i) * g);
+                const float d = ld_f(dz, i);                         // the rounded value, what pass 2 reads
+                s0 += d;
+                s1 += d * v;
+            }
+        }
+        partial[((size_t)blockIdx.x * 2) * C + c] = s0;
+        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = s1;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_kernel(const T *__restrict__ dz, const T *__restrict__ u, const float *__restrict__ a, const float *__restrict__ b,
+                    const float *__restrict__ c0, T *__restrict__ du, size_t n, int C) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        st_f(du, i, a[c] * ld_f(dz, i) + b[c] * ld_f(u, i) + c0[c]);
+    }
+}
+
+size_t bn_workspace_bytes(long long P, int C) { return (size_t)colsum_parts(P) * 2 * C * 4; }
+
+int launch_bn_reduce(const void *u, const void *dy, void *dz, const float *scale, const float *shift, long long P, int C, int act,
+                     int dtype, float *sums, void *ws, hipStream_t s) {
+    const int parts = colsum_parts(P);
+    const long long rows_per = (P + parts - 1) / parts;
+    float *partial = (float *)ws;
+    if (dy == nullptr) {
+        if (dtype == YMX_BF16) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0>), dim3(parts), dim3(256), 0, s, (const bf16_t *)u, (const bf16_t *)nullptr, (bf16_t *)nullptr, scale, shift, partial, P, C, rows_per, act);
+        else hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), dim3(parts), dim3(256), 0, s, (const float *)u, (const float *)nullptr, (float *)nullptr, scale, shift, partial, P, C, rows_per, act);
+    } else {
+        if (dtype == YMX_BF16) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1>), dim3(parts), dim3(256), 0, s, (const bf16_t *)u, (const bf16_t *)dy, (bf16_t *)dz, scale, shift, partial, P, C, rows_per, act);
+        else hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), dim3(parts), dim3(256), 0, s, (const float *)u, (const float *)dy, (float *)dz, scale, shift, partial, P, C, rows_per, act);
+    }
+    int rc = check_launch("bn_reduce");
+    if (rc) return rc;
+    // partial is [parts][2 C]: the two sums of a slab lie side by side, so one ordered pass adds both
+    hipLaunchKernelGGL(sum_partials_small_kernel, dim3((2 * C + 31) / 32), dim3(1024), 0, s, partial, sums, 2 * C, parts);
+    return check_launch("bn_reduce_sum");
+}
+
+int launch_bn_bwd_apply(const void *dz, const void *u, const float *a, const float *b, const float *c, void *du, long long P, int C,
+                        int dtype, hipStream_t s) {
+    const size_t n = (size_t)P * C;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 1 << 16);
+    if (dtype == YMX_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t *)dz, (const bf16_t *)u, a, b, c, (bf16_t *)du, n, C);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float *)dz, (const float *)u, a, b, c, (float *)du, n, C);
+    return check_launch("bn_backward_apply");
+}
+
 // ---- weight gradient --------------------------------------------------------------------------
 // GEMM  dW[ci][co] (per tap) = sum_p X[p + tap][ci] * dZ[p][co]: both operands have the
 // reduction index (pixels) as their SLOW axis in memory, the opposite of what an MFMA lane

@@ -40,16 +40,20 @@ def affine_act(x, scale, shift, act):
 
 
 class BatchNormalization(nn.Module):
-    """Inference-statistics batch norm over the last axis (layers.py:4-15).
+    """Batch norm over the last axis (layers.py:4-15).
 
-    The reference forces ``training = training and trainable`` and then defers to
-    Keras; this package covers the inference form only, so a call that would use
-    batch statistics raises instead of silently normalising differently.
+    The reference forces ``training = training and trainable`` and then defers to Keras:
+    with the flag off (or a frozen layer) the moving statistics normalise, folded into one
+    scale and shift; with it on, the statistics of the batch do, the moving ones are
+    updated (momentum 0.99, Keras' default) and the call is differentiable
+    (yolo_amd.training).  Inside a YOLOConv the flag is ``yolo_amd.training.backprop()``
+    being active, the counterpart of Keras handing ``training=True`` down under model.fit.
     """
 
-    def __init__(self, num_features=None, epsilon=BN_EPSILON):
+    def __init__(self, num_features=None, epsilon=BN_EPSILON, momentum=0.99):
         super().__init__()
         self.epsilon = epsilon
+        self.momentum = momentum
         self.trainable = True
         self.num_features = None
         if num_features is not None:
@@ -70,12 +74,11 @@ class BatchNormalization(nn.Module):
         return scale.contiguous(), shift.contiguous()
 
     def forward(self, x, training=False):
-        if training and self.trainable:
-            raise NotImplementedError("BatchNormalization: batch-statistics (training) mode is not part "
-                                      "of the inference hot path")
         if self.num_features is None:
             self.build(x.shape[-1])
             self.to(x.device)
+        if training and self.trainable:
+            return _training.batch_norm_act(self, _as_nhwc(x), _lib.ACT_NONE)
         scale, shift = self.folded()
         return affine_act(x, scale, shift, _lib.ACT_NONE)
 
@@ -123,6 +126,8 @@ def upsample2x_concat(skip, x, _differentiable=True):
 def spp_concat(x):
     """concat([maxpool13(x), maxpool9(x), maxpool5(x), x], -1), stride-1 SAME pools, in one
     kernel (ymx_spp_concat; /root/reference/backbones.py:254-259)."""
+    if _training.enabled() and x.requires_grad:
+        return _training.spp_concat(x)
     x = _as_nhwc(x)
     b, h, w, c = x.shape
     y = _empty_like_nhwc(x, 4 * c)
@@ -240,17 +245,16 @@ class YOLOConv(nn.Module):
         Layers whose input channels do not take the MFMA kernels (the first: 3) have no
         input-gradient pack; stride-2 layers get the 2x2 depth-to-space form
         (ymx_conv2d_dgrad_s2)."""
-        if self.batch_normalization:
-            raise ValueError("YOLOConv.packed_training: batch normalisation layers are not trained")
+        bn = self.batch_normalization              # the convolution is then linear: no bias, normalisation follows
         dev = self.kernel.device
-        key = (dtype, dev, self.kernel._version, self.bias._version)
+        key = (dtype, dev, self.kernel._version, None if bn else self.bias._version)
         hit = self._packed.get("train")
         if hit is not None and hit[0] == key:
             return hit[1]
         k, cin, cout = self.kernel_size, self.in_channels, self.filters
         if cin % 8:
             wp, _, shift, _ = self.packed(dtype)
-            entry = (wp, shift, None)
+            entry = (wp, None if bn else shift, None)
         else:
             _lib.require_gpu(self.kernel)
             L = _lib.lib()
@@ -264,7 +268,7 @@ class YOLOConv(nn.Module):
             wdp = torch.empty(nb, dtype=torch.uint8, device=dev)
             src = self.kernel.detach().float().contiguous()
             _lib.launch("ymx_pack_weights_pair", wp, _lib.ptr(src), _lib.ptr(wp), _lib.ptr(wdp), k, cin, cout, coutp, stride, code)
-            entry = (wp, self.bias.detach().float().contiguous(), wdp, src)
+            entry = (wp, None if bn else self.bias.detach().float().contiguous(), wdp, src)
         self._packed["train"] = (key, entry)
         return entry
 

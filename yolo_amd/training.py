@@ -23,8 +23,10 @@ Use::
     loss.backward()              # .grad of every kernel and bias, fp32
 
 Outside the context (the default) the layers run the fused inference kernels and build no
-graph.  Batch normalisation in training mode is not provided (the networks of the reference
-use bias, layers.py:61).
+graph.  A YOLOConv with batch normalisation (layers.py:65-68) runs as a linear convolution
+followed by ``batch_norm_act``: batch statistics, gamma / beta, activation and shortcut, with
+the moving statistics updated as Keras does (frozen layers, ``trainable = False``, keep
+normalising with the moving statistics, layers.py:11-15).
 """
 import threading
 
@@ -161,6 +163,8 @@ class _ConvBlock(torch.autograd.Function):
             raise ValueError("yolo_amd.training: back-propagation is provided for bfloat16 networks")
         k, cin, cout = layer.kernel_size, layer.in_channels, layer.filters
         stride = 2 if layer.downsample else 1
+        act = _lib.ACT_NONE if layer.batch_normalization else layer.act_code      # normalisation and activation follow separately
+        ctx.act = act
         x_dtype_in = x.dtype
         x = x.contiguous()
         if cin % 8 == 0 and x.dtype != cdt:
@@ -168,18 +172,18 @@ class _ConvBlock(torch.autograd.Function):
         entry = layer.packed_training(cdt)
         wp, shift = entry[0], entry[1]
         sc = None if shortcut is None else shortcut.to(cdt).contiguous()
-        if layer.act_code != _lib.ACT_NONE:
+        if act != _lib.ACT_NONE:
             b, h, w, _ = x.shape
             oh, ow = layer.output_hw(h, w)
             z = _empty((b, oh, ow, cout), x, cdt)
             y = torch.empty_like(z)
             _lib.launch("ymx_conv2d_fused_z", x, _lib.ptr(x), _lib.ptr(wp), None, _lib.ptr(shift), _lib.ptr(sc), _lib.ptr(y), _lib.ptr(z),
-                        b, h, w, cin, cout, k, stride, layer.act_code, _lib.dtype_code(x.dtype))
+                        b, h, w, cin, cout, k, stride, act, _lib.dtype_code(x.dtype))
         else:
             z = _conv(x, wp, shift, cin, cout, k, stride, cdt, cdt)
             if sc is not None:
                 y = torch.empty_like(z)
-                _lib.launch("ymx_act_apply", z, _lib.ptr(z), _lib.ptr(sc), _lib.ptr(y), z.numel(), layer.act_code, _lib.dtype_code(cdt))
+                _lib.launch("ymx_act_apply", z, _lib.ptr(z), _lib.ptr(sc), _lib.ptr(y), z.numel(), act, _lib.dtype_code(cdt))
             else:
                 y = z
         ctx.save_for_backward(x, z, kernel)
@@ -194,6 +198,7 @@ class _ConvBlock(torch.autograd.Function):
     def backward(ctx, dy):
         x, z, kernel = ctx.saved_tensors
         layer = ctx.layer
+        act = ctx.act
         cdt = torch.bfloat16
         code = _lib.dtype_code(cdt)
         k, cin, cout = layer.kernel_size, layer.in_channels, layer.filters
@@ -210,16 +215,16 @@ class _ConvBlock(torch.autograd.Function):
         # bucket's all-reduce as soon as its last gradient is there; autograd gets None
         kslot = _slot(layer.kernel) if ctx.needs_input_grad[1] else None
         bslot = _slot(layer.bias) if ctx.needs_input_grad[2] else None
-        if layer.act_code != _lib.ACT_NONE:
+        if act != _lib.ACT_NONE:
             dz = torch.empty_like(z)
-            nb = L.ymx_act_backward_bias_workspace_bytes(npix, cout, layer.act_code, code) if ctx.needs_input_grad[2] else 0
+            nb = L.ymx_act_backward_bias_workspace_bytes(npix, cout, act, code) if ctx.needs_input_grad[2] else 0
             if nb:                       # derivative of the activation and the bias gradient in one pass
                 dbias = bslot[1] if bslot is not None else torch.empty((cout,), device=x.device, dtype=torch.float32)
                 ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)
-                _lib.launch("ymx_act_backward_bias", z, _lib.ptr(z), _lib.ptr(dy), _lib.ptr(dz), npix, cout, layer.act_code, code,
+                _lib.launch("ymx_act_backward_bias", z, _lib.ptr(z), _lib.ptr(dy), _lib.ptr(dz), npix, cout, act, code,
                             _lib.ptr(dbias), _lib.ptr(ws), nb)
             else:
-                _lib.launch("ymx_act_backward", z, _lib.ptr(z), _lib.ptr(dy), _lib.ptr(dz), z.numel(), layer.act_code, code)
+                _lib.launch("ymx_act_backward", z, _lib.ptr(z), _lib.ptr(dy), _lib.ptr(dz), z.numel(), act, code)
         else:
             dz = dy
         # channel counts the MFMA kernels take (multiples of 8): zero padding changes nothing
@@ -306,11 +311,90 @@ class _ConvBlock(torch.autograd.Function):
 def conv_block(layer, x, shortcut=None, link=None):
     """YOLOConv forward that autograd can differentiate (called by YOLOConv.forward inside
     ``backprop()``).  link: the GradLink of the ResidialBlock the layer belongs to."""
-    if layer.batch_normalization:
-        raise ValueError("yolo_amd.training: batch normalisation in training mode is not provided")
     if layer.act_fn is not None:
         raise ValueError("yolo_amd.training: callable activations are not differentiated")
+    if layer.batch_normalization:
+        u = _ConvBlock.apply(x, layer.kernel, None, None, layer, None)            # linear, no bias (layers.py:61)
+        return batch_norm_act(layer.bn, u, layer.act_code, shortcut)
     return _ConvBlock.apply(x, layer.kernel, layer.bias, shortcut, layer, link)
+
+
+class _BatchNormAct(torch.autograd.Function):
+    """y = act(gamma * (u - mean) / sqrt(var + eps) + beta) + shortcut over the last axis of u, mean and
+    var the batch's own (trainable layer) or the moving ones (frozen layer: constants)."""
+
+    @staticmethod
+    def forward(ctx, u, gamma, beta, shortcut, bn, act):
+        if u.dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("batch_norm_act: bfloat16 or float32 tensors")
+        u = u.contiguous()
+        c = u.shape[-1]
+        n = u.numel() // c
+        code = _lib.dtype_code(u.dtype)
+        L = _lib.lib()
+        frozen = not bn.trainable
+        if frozen:
+            mean, var = bn.moving_mean.float(), bn.moving_variance.float()
+        else:
+            nb = L.ymx_bn_workspace_bytes(n, c)
+            ws = torch.empty((nb,), device=u.device, dtype=torch.uint8)
+            sums = torch.empty((2 * c,), device=u.device, dtype=torch.float32)
+            _lib.launch("ymx_bn_stats", u, _lib.ptr(u), n, c, code, _lib.ptr(sums), _lib.ptr(ws), nb)
+            mean = sums[:c] / n
+            var = (sums[c:] / n - mean * mean).clamp_min_(0.0)               # biased, as Keras normalises
+            with torch.no_grad():                                             # the moving statistics Keras keeps for inference
+                m = bn.momentum
+                bn.moving_mean.mul_(m).add_(mean.to(bn.moving_mean.dtype), alpha=1.0 - m)
+                bn.moving_variance.mul_(m).add_((var * (n / max(n - 1, 1))).to(bn.moving_variance.dtype), alpha=1.0 - m)
+        inv = torch.rsqrt(var + bn.epsilon)
+        scale = (gamma.detach().float() * inv).contiguous()
+        shift = (beta.detach().float() - mean * scale).contiguous()
+        sc = None if shortcut is None else shortcut.to(u.dtype).contiguous()
+        y = torch.empty_like(u)
+        _lib.launch("ymx_bn_act_forward", u, _lib.ptr(u), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(sc), _lib.ptr(y), n, c, act, code)
+        ctx.save_for_backward(u, scale, shift, mean, inv, gamma)
+        ctx.act, ctx.frozen = act, frozen
+        ctx.shortcut_dtype = None if shortcut is None else shortcut.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, scale, shift, mean, inv, gamma = ctx.saved_tensors
+        c = u.shape[-1]
+        n = u.numel() // c
+        code = _lib.dtype_code(u.dtype)
+        L = _lib.lib()
+        dy = dy.to(u.dtype).contiguous()
+        dz = torch.empty_like(u)
+        nb = L.ymx_bn_workspace_bytes(n, c)
+        ws = torch.empty((nb,), device=u.device, dtype=torch.uint8)
+        sums = torch.empty((2 * c,), device=u.device, dtype=torch.float32)
+        _lib.launch("ymx_bn_act_backward", u, _lib.ptr(u), _lib.ptr(dy), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(dz), n, c, ctx.act, code,
+                    _lib.ptr(sums), _lib.ptr(ws), nb)
+        dbeta = sums[:c]
+        dgamma = inv * (sums[c:] - mean * dbeta)
+        g = gamma.detach().float()
+        a = (g * inv).contiguous()
+        if ctx.frozen:                                   # constants: du = scale * dz, no parameter gradients through the statistics
+            b = torch.zeros_like(a)
+            c0 = torch.zeros_like(a)
+        else:
+            b = (-g * inv * inv * dgamma / n).contiguous()
+            c0 = (g * inv * (inv * mean * dgamma - dbeta) / n).contiguous()
+        du = None
+        if ctx.needs_input_grad[0]:
+            du = torch.empty_like(u)
+            _lib.launch("ymx_bn_backward_apply", u, _lib.ptr(dz), _lib.ptr(u), _lib.ptr(a), _lib.ptr(b), _lib.ptr(c0), _lib.ptr(du), n, c, code)
+        dsc = dy.to(ctx.shortcut_dtype) if (ctx.shortcut_dtype is not None and ctx.needs_input_grad[3]) else None
+        return (du, dgamma.to(gamma.dtype) if ctx.needs_input_grad[1] else None, dbeta.clone() if ctx.needs_input_grad[2] else None,
+                dsc, None, None)
+
+
+def batch_norm_act(bn, u, act=_lib.ACT_NONE, shortcut=None):
+    """Training-mode call of a yolo_amd.layers.BatchNormalization on u [..., C] (a GPU tensor,
+    bfloat16 or float32), with an activation code and a shortcut applied in the same pass."""
+    _lib.require_gpu(u)
+    return _BatchNormAct.apply(u, bn.gamma, bn.beta, shortcut, bn, act)
 
 
 class _UpsampleConcat(torch.autograd.Function):
@@ -336,3 +420,33 @@ class _UpsampleConcat(torch.autograd.Function):
 
 def upsample_concat(skip, x):
     return _UpsampleConcat.apply(skip, x)
+
+
+class _SppConcat(torch.autograd.Function):
+    """concat([maxpool13, maxpool9, maxpool5, x]) (backbones.py:254-259) with the argmax of every
+    pooled value kept for the backward pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        b, h, w, c = x.shape
+        y = torch.empty((b, h, w, 4 * c), device=x.device, dtype=x.dtype)
+        arg = torch.empty((b, h, w, 3, c), device=x.device, dtype=torch.uint8)
+        _lib.launch("ymx_spp_concat_train", x, _lib.ptr(x), _lib.ptr(y), _lib.ptr(arg), b, h, w, c, _lib.dtype_code(x.dtype))
+        ctx.save_for_backward(arg)
+        ctx.shape = (b, h, w, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        b, h, w, c = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((b, h, w, c), device=dy.device, dtype=dy.dtype)
+        _lib.launch("ymx_spp_concat_backward", dy, _lib.ptr(dy), _lib.ptr(arg), _lib.ptr(dx), b, h, w, c, _lib.dtype_code(dy.dtype))
+        return dx
+
+
+def spp_concat(x):
+    _lib.require_gpu(x)
+    return _SppConcat.apply(x)
