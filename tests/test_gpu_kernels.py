@@ -328,8 +328,9 @@ def test_layers_standalone():
     want = (x - bn.moving_mean) / torch.sqrt(bn.moving_variance + 1e-3) * bn.gamma.detach() + bn.beta.detach()
     got = bn.to(DEV)(x.to(DEV)).cpu()
     assert rel_err(got.numpy(), want.numpy()) < 1e-5
-    with pytest.raises(NotImplementedError):
-        bn(x.to(DEV), training=True)
+    # training=True normalises with the batch's own statistics (tests/test_gpu_train_bn_csp.py covers the numbers)
+    tr = bn(x.to(DEV), training=True).detach().cpu()
+    assert float(((tr - bn.beta.detach().cpu()) / bn.gamma.detach().cpu()).mean(dim=(0, 1, 2)).abs().max()) < 1e-4
     r = layers.RouteGroup(2, 1)(x.to(DEV))
     assert r.shape == (2, 5, 7, 8) and torch.equal(r.cpu(), x[..., 8:])
     # callable activation runs after the kernel
