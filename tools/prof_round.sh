@@ -8,8 +8,8 @@ export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
-BARGS="bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-profile --split off"
-PARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --split off"
+BARGS="bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-profile --no-extra-legs --min-seconds 0 --split off"
+PARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-extra-legs --min-seconds 0 --split off"
 SARGS="bench.py --workload nms-stress --steps 10 --warmup 2 --no-cpu-baseline"
 
 # detector: kernel trace of the serial program, then the default (concurrent sub-batches)
@@ -29,7 +29,10 @@ cp $(find $O/s_trace -name '*kernel_stats.csv' | head -1) $O/${TAG}_stress_kerne
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/s_fetch -- python3 $SARGS > $O/s_fetch.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/s_write -- python3 $SARGS > $O/s_write.log 2>&1
 python3 tools/pmc_summary.py $(find $O/s_fetch -name '*counter_collection.csv' | head -1) $(find $O/s_write -name '*counter_collection.csv' | head -1) 2 > $O/${TAG}_pmc_traffic_stress.json
+# training step: kernel trace (weight gradients on the main stream so that per-kernel times add up)
+OVERLAP=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/tr -o tr -- python3 tools/train_step_time.py 64 416 4 > $O/tr.log 2>&1
+(echo "rocprofv3 --kernel-trace of OVERLAP=0 tools/train_step_time.py 64 416 4 (one MI355X; 5 steps incl. the first)
 # drop the bulky raw outputs, keep the summaries
-rm -rf $O/t_off $O/p_fetch $O/p_write $O/p_mfma $O/s_trace $O/s_fetch $O/s_write
+rm -rf $O/t_off $O/p_fetch $O/p_write $O/p_mfma $O/s_trace $O/s_fetch $O/s_write $O/tr
 ls -la $O
 head -14 $O/${TAG}_bench_kernel_trace_summary.txt
