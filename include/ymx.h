@@ -363,6 +363,14 @@ int ymx_bias_grad(const void *dz, long long n_pix, int C, int ld, int dtype, flo
 size_t ymx_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride);
 int ymx_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw, int B, int H, int W,
                    int Cin, int Cout, int k, int stride, void *workspace, size_t ws_bytes, void *stream);
+/* Weight gradient of a 3x3 stride-1 layer with at most 3 input channels (the first layer of the
+ * backbones, /root/reference/backbones.py:10): x [B,H,W,Cin] fp32 or bf16 as it is (no channel
+ * padding), dz [B,H,W,dz_ld] bf16 (Cout a multiple of 8, at most 64), dw [3][3][Cin][Cout] fp32.
+ * ymx_conv_wgrad_first_workspace_bytes returns 0 for shapes this entry point does not take (use
+ * ymx_conv_wgrad on channel-padded tensors then).  Deterministic (ordered partial sums). */
+size_t ymx_conv_wgrad_first_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int ymx_conv_wgrad_first(const void *x, int x_dtype, const void *dz, int dz_ld, float *dw, int B, int H, int W,
+                         int Cin, int Cout, void *workspace, size_t ws_bytes, void *stream);
 /* Which kernel ymx_conv_wgrad would take for dense tensors of this shape under the calling
  * thread's "wgrad_variant": "wgrad_slab" (all taps from one resident slab), "wgrad_dma" (per
  * tap, LDS-DMA) or "wgrad_reg" (per tap, register-staged); NULL on a bad shape.  No counterpart

@@ -554,3 +554,44 @@ def test_stride2_input_gradient_depth_to_space(case):
     e = _scaled_err(dx.float().cpu(), xo.grad)
     print("stride-2 input gradient, %s: error %.2e of the gradient's scale" % (family, e))
     assert e < 1e-2
+
+
+FIRST_CASES = [   # B, H, W, Cin, Cout, fp32 image
+    (2, 416, 416, 3, 32, True),        # the detector's first layer
+    (3, 37, 45, 3, 32, False),         # width off the 32-pixel steps, bf16 input
+    (1, 64, 100, 1, 64, True),         # one input channel, four output blocks
+    (2, 20, 33, 2, 24, True),          # output channels off the block size
+]
+
+
+@pytest.mark.parametrize("case", range(len(FIRST_CASES)))
+def test_first_layer_weight_gradient(case):
+    """ymx_conv_wgrad_first through the C ABI against the fp32 CPU derivative of the oracle's
+    convolution with respect to its kernel (same inputs rounded to bf16, as the kernel rounds the
+    image): 1e-4 of the gradient's scale, bit-identical between two launches."""
+    from yolo_amd import _lib
+    B, H, W, cin, cout, f32 = FIRST_CASES[case]
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(1500 + case)
+    x = N.bf16_round(torch.rand(B, H, W, cin, generator=g))
+    dz = N.bf16_round(torch.randn(B, H, W, cout, generator=g))
+    wo = torch.zeros(3, 3, cin, cout, requires_grad=True)
+    yo = N.yolo_conv(x, {"kernel": wo, "bias": torch.zeros(cout)}, False, None)
+    (yo * dz).sum().backward()
+    xg = x.to(DEV) if f32 else x.to(DEV).bfloat16()
+    dzg = dz.to(DEV).bfloat16()
+    nb = L.ymx_conv_wgrad_first_workspace_bytes(B, H, W, cin, cout)
+    assert nb > 0
+    outs = []
+    for _ in range(2):
+        ws = torch.full((nb,), 0xff, dtype=torch.uint8, device=DEV)
+        dw = torch.full((3, 3, cin, cout), float("nan"), device=DEV)
+        _lib.launch("ymx_conv_wgrad_first", xg, _lib.ptr(xg), _lib.dtype_code(xg.dtype), _lib.ptr(dzg), 0, _lib.ptr(dw), B, H, W, cin, cout,
+                    _lib.ptr(ws), nb)
+        outs.append(dw)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    e = _scaled_err(outs[0].cpu(), wo.grad)
+    print("first-layer weight gradient: error %.2e of the gradient's scale" % e)
+    assert e < 1e-4
+    assert L.ymx_conv_wgrad_first_workspace_bytes(B, H, W, 8, cout) == 0          # other shapes: the general kernels

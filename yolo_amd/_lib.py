@@ -35,6 +35,8 @@ SIGNATURES = {
     "ymx_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "ymx_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ymx_pack_weights_dgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ymx_conv_wgrad_first_workspace_bytes": (_sz, [_i] * 5),
+    "ymx_conv_wgrad_first": (_i, [_vp, _i, _vp, _i, _vp] + [_i] * 5 + [_vp, _sz, _vp]),
     "ymx_spp_concat_train": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ymx_spp_concat_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ymx_bn_workspace_bytes": (_sz, [_ll, _i]),

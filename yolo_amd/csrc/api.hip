@@ -592,6 +592,25 @@ int ymx_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw
     return launch_conv_wgrad(x, x_ld, dz, dz_ld, dw, B, H, W, Cin, Cout, k, stride, workspace, (hipStream_t)stream);
 }
 
+size_t ymx_conv_wgrad_first_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    return conv_wgrad_first_workspace_bytes(B, H, W, Cin, Cout);
+}
+
+int ymx_conv_wgrad_first(const void *x, int x_dtype, const void *dz, int dz_ld, float *dw, int B, int H, int W, int Cin, int Cout,
+                         void *workspace, size_t ws_bytes, void *stream) {
+    if (!x || !dz || !dw || !workspace) return fail(YMX_EARG, "conv_wgrad_first: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(YMX_EARG, "conv_wgrad_first: non-positive size");
+    if (x_dtype != YMX_F32 && x_dtype != YMX_BF16) return fail(YMX_EARG, "conv_wgrad_first: x_dtype %d", x_dtype);
+    if (!conv_wgrad_first_supported(B, H, W, Cin, Cout))
+        return fail(YMX_EUNSUPPORTED, "conv_wgrad_first: %d -> %d channels at width %d (at most 3 input channels, 64 output channels in multiples of 8)", Cin, Cout, W);
+    if (dz_ld != 0 && (dz_ld < Cout || dz_ld % 8)) return fail(YMX_EARG, "conv_wgrad_first: dz pixel stride must be a multiple of 8 elements");
+    if (!aligned16(dz) || (((uintptr_t)dw) & 3) || (((uintptr_t)workspace) & 3)) return fail(YMX_EARG, "conv_wgrad_first: alignment");
+    const size_t need = conv_wgrad_first_workspace_bytes(B, H, W, Cin, Cout);
+    if (ws_bytes < need) return fail(YMX_EWORKSPACE, "conv_wgrad_first: workspace %zu < %zu bytes", ws_bytes, need);
+    return launch_conv_wgrad_first(x, x_dtype == YMX_F32 ? 1 : 0, dz, dz_ld, dw, B, H, W, Cin, Cout, workspace, (hipStream_t)stream);
+}
+
 // CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), eight bytes per step: host code, for
 // the record framing of yolo_amd/tfrecord.py (records hold megabytes of tensor data).
 unsigned ymx_crc32c(const void *data, size_t n, unsigned crc) {

@@ -266,6 +266,10 @@ size_t conv_wgrad_workspace_bytes(int k, int Cin, int Cout, long long P);
 int launch_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw, int B, int H, int W, int Cin, int Cout, int k,
                       int stride, void *ws, hipStream_t s);
 const char *conv_wgrad_label(int B, int H, int W, int Cin, int Cout, int k, int stride);
+bool conv_wgrad_first_supported(int B, int H, int W, int Cin, int Cout);
+size_t conv_wgrad_first_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int launch_conv_wgrad_first(const void *x, int x_f32, const void *dz, int dz_ld, float *dw, int B, int H, int W, int Cin, int Cout, void *ws,
+                            hipStream_t s);
 int launch_upsample2x_bwd(const void *dy, void *dx, int B, int H, int W, int C, int dy_ld, int c_off, int dtype, hipStream_t s);
 size_t yolo_loss_workspace_bytes(int B, int S);
 int launch_yolo_loss_grad(const float *conv, int conv_ld, const float *label, long long label_stride, const float *bboxes,

@@ -1093,6 +1093,174 @@ int launch_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float 
     return check_launch("conv_wgrad_reduce");
 }
 
+// ---- weight gradient of the first layer (3 input channels) ------------------------------------------
+// dW[tap][ci][co] = sum_p x[p + tap][ci] * dz[p][co] with 9 * 3 = 27 (tap, ci) rows and up to 64
+// output channels: 864-1728 sums over ~10^7 pixels, i.e. a reduction that should cost the time of
+// reading dz once.  The general kernels pad the image to 8 channels (a copy) and leave all but one
+// wave of a workgroup without arithmetic.  Here a workgroup walks image rows; per row it stages,
+// in LDS and PLANAR (one run of pixels per channel), the three input rows it touches -- once per
+// horizontal tap offset, so that every fragment read is an aligned 16 bytes -- and the dz row
+// transposed the same way; then both MFMA operands are plain 16-byte LDS reads:
+//   A[m = (tap, ci)][k = pixel]   from XA[s][r][ci][col],  holding x[row + r - 1][col + s - 1][ci]
+//   B[k = pixel][n = co]          from DZ[co][col]
+// Each wave takes every fourth 32-pixel step of the row and keeps its own accumulators; every
+// wave of every workgroup writes one partial result, added in order by sum_partials.
+struct WgradFirstArgs {
+    const void *x;              // [B][H][W][Cin] fp32 or bf16, dense
+    const bf16_t *dz;           // [B][H][W][dz_ld] bf16
+    float *partial;             // [gridDim.x * 4][9 * Cin * Cout]
+    int B, H, W, Cin, Cout, dz_ld, Wp, x_f32;
+};
+
+template <int NB>               // 16-channel blocks of dz handled (Cout <= 16 * NB)
+__global__ void __launch_bounds__(256)
+conv_wgrad_first_kernel(const WgradFirstArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t *XA = (bf16_t *)smem;                                  // [3 s][3 r][3 ci][Wp]
+    bf16_t *DZ = XA + 27 * a.Wp;                                  // [16 NB][Wp]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int Wp = a.Wp, W = a.W, Cin = a.Cin;
+    const int M = 9 * Cin;
+    f32x4_t acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // this lane's operand rows: A row m = mb * 16 + (lane & 15) -> (tap, ci) -> plane of XA
+    unsigned aoff[2];
+    bool alive[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int m = mb * 16 + (lane & 15);
+        alive[mb] = m < M;
+        const int tap = alive[mb] ? m / Cin : 0, ci = alive[mb] ? m - tap * Cin : 0;
+        const int r = tap / 3, sx = tap - r * 3;
+        aoff[mb] = (unsigned)((((sx * 3 + r) * 3 + ci) * Wp + 8 * (lane >> 4)) * 2);
+    }
+    const unsigned boff = (unsigned)(((lane & 15) * Wp + 8 * (lane >> 4)) * 2);
+    // XA and DZ start as zeros: the columns [W, Wp) of every plane are never written below (the MFMAs
+    // run over whole 32-pixel steps, so they must hold finite values, and dz's must be zero), nor are
+    // the two border columns that stand for x[-1] and x[W]
+    for (int i = t; i < (27 + 16 * NB) * Wp; i += 256) XA[i] = 0;
+    const int nrows = a.B * a.H;
+    const int row_elems = W * Cin;                                  // elements of one image row
+    const int nch8 = a.Cout >> 3;
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int b = row / a.H, ih = row - b * a.H;
+        __syncthreads();                                           // the previous row's fragment reads (or the zero fill) are done
+        // x planes, source driven: the three image rows are read once, coalesced, eight elements per thread in
+        // flight; element (r, col, ci) goes to XA[s][r][ci][col - s + 1] for the three horizontal tap offsets s
+        for (int i0 = 0; i0 < 3 * row_elems; i0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256 + t;
+                v[u] = 0.0f;
+                if (i < 3 * row_elems) {
+                    const int r = i / row_elems, e = i - r * row_elems, yy = ih + r - 1;
+                    if (yy >= 0 && yy < a.H) {
+                        const size_t g = ((size_t)b * a.H + yy) * row_elems + e;
+                        v[u] = a.x_f32 ? ((const float *)a.x)[g] : bf16_to_f32(((const bf16_t *)a.x)[g]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256 + t;
+                if (i < 3 * row_elems) {
+                    const int r = i / row_elems, e = i - r * row_elems;
+                    const int col = e / Cin, ci = e - col * Cin;
+                    const bf16_t q = f32_to_bf16(v[u]);
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) {
+                        const int c = col - sx + 1;
+                        if (c >= 0 && c < W) XA[((sx * 3 + r) * 3 + ci) * Wp + c] = q;
+                    }
+                }
+            }
+        }
+        // dz row: 16-byte chunks (8 channels of one pixel), four per thread in flight, scattered into the channel
+        // planes; consecutive lanes take consecutive pixels of one channel group, so the 2-byte stores of a wave
+        // fill consecutive LDS words
+        const bf16_t *zrow = a.dz + ((size_t)b * a.H + ih) * W * a.dz_ld;
+        for (int i0 = 0; i0 < W * nch8; i0 += 256 * 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 + t;
+                v[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (i < W * nch8) {
+                    const int c8 = i / W, px = i - c8 * W;
+                    v[u] = *(const uint4 *)(zrow + (size_t)px * a.dz_ld + c8 * 8);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 + t;
+                if (i < W * nch8) {
+                    const int c8 = i / W, px = i - c8 * W;
+                    const uint32_t w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        DZ[(c8 * 8 + 2 * e) * Wp + px] = (bf16_t)(w4[e] & 0xffffu);
+                        DZ[(c8 * 8 + 2 * e + 1) * Wp + px] = (bf16_t)(w4[e] >> 16);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int col0 = wave * 32; col0 < Wp; col0 += 128) {
+            uint4 fa[2], fb[NB];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+                fa[mb] = alive[mb] ? *(const uint4 *)(smem + aoff[mb] + col0 * 2) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) fb[nb] = *(const uint4 *)((const char *)DZ + boff + (nb * 16 * Wp + col0) * 2);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[mb]), __builtin_bit_cast(bf16x8_t, fb[nb]),
+                                                                          acc[mb][nb], 0, 0, 0);
+        }
+    }
+    float *out = a.partial + ((size_t)blockIdx.x * 4 + wave) * M * a.Cout;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mb * 16 + 4 * (lane >> 4) + r, n = nb * 16 + (lane & 15);
+                if (m < M && n < a.Cout) out[(size_t)m * a.Cout + n] = acc[mb][nb][r];
+            }
+}
+
+static int wgrad_first_grid(int B, int H) { return std::min(B * H, 768); }        // three workgroups per CU
+bool conv_wgrad_first_supported(int B, int H, int W, int Cin, int Cout) {
+    const int Wp = (W + 31) / 32 * 32, nb = (Cout + 15) / 16;
+    return Cin >= 1 && Cin <= 3 && Cout % 8 == 0 && Cout <= 64 && (long long)B * H < (1LL << 30) && (27 + 16 * nb) * Wp * 2 <= 52 * 1024;
+}
+size_t conv_wgrad_first_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (!conv_wgrad_first_supported(B, H, W, Cin, Cout)) return 0;
+    return (size_t)wgrad_first_grid(B, H) * 4 * 9 * Cin * Cout * 4;
+}
+int launch_conv_wgrad_first(const void *x, int x_f32, const void *dz, int dz_ld, float *dw, int B, int H, int W, int Cin, int Cout, void *ws,
+                            hipStream_t s) {
+    WgradFirstArgs a;
+    a.x = x; a.dz = (const bf16_t *)dz; a.partial = (float *)ws;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.dz_ld = dz_ld > 0 ? dz_ld : Cout; a.x_f32 = x_f32;
+    a.Wp = (W + 31) / 32 * 32;
+    const int nb = (Cout + 15) / 16, grid = wgrad_first_grid(B, H);
+    const int lds = (27 + 16 * nb) * a.Wp * 2;
+    if (nb <= 2) hipLaunchKernelGGL(conv_wgrad_first_kernel<2>, dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(conv_wgrad_first_kernel<4>, dim3(grid), dim3(256), lds, s, a);
+    int rc = check_launch("conv_wgrad_first");
+    if (rc) return rc;
+    launch_sum_partials((const float *)ws, dw, (size_t)9 * Cin * Cout, grid * 4, s);
+    return check_launch("conv_wgrad_first_reduce");
+}
+
 // ---- adjoint of the bilinear x2 resize --------------------------------------------------------
 // Forward (elementwise.hip): src = (o + 0.5) / 2 - 0.5, lo = max(floor(src), 0), hi = min(ceil(src), n - 1),
 // y[o] = x[lo] * (1 - f) + x[hi] * f, f = src - floor(src).  Input i therefore receives from outputs

@@ -244,14 +244,29 @@ class _ConvBlock(torch.autograd.Function):
         dkernel = None
         side = None
         if ctx.needs_input_grad[1]:
-            xp = _pad_channels(x.to(cdt))
-            cinp = xp.shape[-1]
+            # the first layer (3 input channels) has a kernel of its own that reads the image as it is
+            nbf = 0
+            if k == 3 and stride == 1 and cin <= 3 and x.dtype in (torch.float32, torch.bfloat16):
+                nbf = L.ymx_conv_wgrad_first_workspace_bytes(b, h, w, cin, coutp)
+            if nbf:
+                xp, cinp, nb = x, cin, nbf
+            else:
+                xp = _pad_channels(x.to(cdt))
+                cinp = xp.shape[-1]
+                nb = L.ymx_conv_wgrad_workspace_bytes(b, h, w, cinp, coutp, k, stride)
             direct = kslot is not None and cinp == cin and coutp == cout
             dwp = kslot[1] if direct else torch.empty((k, k, cinp, coutp), device=x.device, dtype=torch.float32)
-            nb = L.ymx_conv_wgrad_workspace_bytes(b, h, w, cinp, coutp, k, stride)
             ws = torch.empty((max(nb, 16),), device=x.device, dtype=torch.uint8)
             if trace is not None:
-                trace.append(L.ymx_conv_wgrad_kernel_label(b, h, w, cinp, coutp, k, stride).decode())
+                trace.append("wgrad_first" if nbf else L.ymx_conv_wgrad_kernel_label(b, h, w, cinp, coutp, k, stride).decode())
+
+            def launch_wgrad():
+                if nbf:
+                    _lib.launch("ymx_conv_wgrad_first", xp, _lib.ptr(xp), _lib.dtype_code(xp.dtype), _lib.ptr(dzp), 0, _lib.ptr(dwp), b, h, w, cin, coutp,
+                                _lib.ptr(ws), nb)
+                else:
+                    _lib.launch("ymx_conv_wgrad", xp, _lib.ptr(xp), 0, _lib.ptr(dzp), 0, _lib.ptr(dwp), b, h, w, cinp, coutp, k, stride,
+                                _lib.ptr(ws), nb)
             # the weight gradient and the input gradient of a block are independent: the former
             # runs on a second stream while this one goes on with the latter
             side = _side_stream(x.device) if (overlap_wgrad and ctx.needs_input_grad[0]) else None
@@ -261,11 +276,9 @@ class _ConvBlock(torch.autograd.Function):
                 for t_ in (xp, dzp, dwp, ws):
                     t_.record_stream(side)
                 with torch.cuda.stream(side):
-                    _lib.launch("ymx_conv_wgrad", xp, _lib.ptr(xp), 0, _lib.ptr(dzp), 0, _lib.ptr(dwp), b, h, w, cinp, coutp, k, stride,
-                                _lib.ptr(ws), nb)
+                    launch_wgrad()
             else:
-                _lib.launch("ymx_conv_wgrad", xp, _lib.ptr(xp), 0, _lib.ptr(dzp), 0, _lib.ptr(dwp), b, h, w, cinp, coutp, k, stride,
-                            _lib.ptr(ws), nb)
+                launch_wgrad()
         dx = None
         if ctx.needs_input_grad[0]:
             # d loss / d x = conv(dz, kernel flipped over the taps, input and output channels swapped)
