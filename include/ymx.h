@@ -61,7 +61,8 @@ const char *ymx_last_error(void);
  * tile of the resident-slab 3x3 kernel (0, the default: 192 where that shortens the launch,
  * else 256; 192 or 256 force one; rows longer than 59 pixels always take 192).
  * "wgrad_variant": 0 (the default) lets ymx_conv_wgrad choose: the all-taps LDS-DMA kernel for
- * 3x3 stride 1 on rows up to 459 pixels, else the per-tap LDS-DMA kernel, both for x and dz
+ * 3x3 stride 1 on rows up to 459 pixels, the all-taps planar-staged kernel for 3x3 stride 2
+ * with up to 32 input channels, else the per-tap LDS-DMA kernel, both for x and dz
  * under 2 GB, else the register-staged kernel; 1 forces the register-staged kernel, 2 the
  * per-tap LDS-DMA kernel (where the tensors allow it).  All forward kernels add the K terms in
  * the same order: forward results do not depend on these options (the weight-gradient kernels
@@ -372,8 +373,9 @@ size_t ymx_conv_wgrad_first_workspace_bytes(int B, int H, int W, int Cin, int Co
 int ymx_conv_wgrad_first(const void *x, int x_dtype, const void *dz, int dz_ld, float *dw, int B, int H, int W,
                          int Cin, int Cout, void *workspace, size_t ws_bytes, void *stream);
 /* Which kernel ymx_conv_wgrad would take for dense tensors of this shape under the calling
- * thread's "wgrad_variant": "wgrad_slab" (all taps from one resident slab), "wgrad_dma" (per
- * tap, LDS-DMA) or "wgrad_reg" (per tap, register-staged); NULL on a bad shape.  No counterpart
+ * thread's "wgrad_variant": "wgrad_slab" (all taps from one resident slab), "wgrad_s2" (all taps,
+ * stride 2, planar staging), "wgrad_dma" (per tap, LDS-DMA) or "wgrad_reg" (per tap,
+ * register-staged); NULL on a bad shape.  No counterpart
  * in the reference; for tests and tuning tools. */
 const char *ymx_conv_wgrad_kernel_label(int B, int H, int W, int Cin, int Cout, int k, int stride);
 int ymx_upsample2x_backward(const void *dy, void *dx, int B, int H, int W, int C, int dy_ld, int c_off,

@@ -32,6 +32,7 @@ CASES = [   # B, H, W, Cin, Cout, k, downsample, act, shortcut
     (1, 52, 52, 64, 128, 3, True, "leaky", False),        # stride 2 at a layer's real width
     (2, 26, 30, 40, 72, 3, True, "mish", False),          # the same with channel counts off the tile sizes
     (2, 12, 8, 16, 255, 3, True, None, False),            # and an output channel count that is padded (255 -> 256)
+    (2, 21, 19, 24, 40, 3, True, "mish", False),           # all-taps stride-2 weight gradient: odd sizes, partial channel tiles
 ]
 
 
@@ -108,7 +109,8 @@ FULL_LAYERS = [   # B, H, Cin, Cout, k, stride: the detector's own layer shapes 
     (1, 104, 64, 128, 3, 1),       # 512-row ring
     (1, 208, 32, 64, 3, 1),        # 1024-row ring
     (1, 416, 8, 32, 3, 1),         # first layer (channels padded 3 -> 8): one live wave per workgroup
-    (1, 416, 32, 64, 3, 2),        # stride 2: per-tap kernels
+    (1, 416, 32, 64, 3, 2),        # stride 2, 32 input channels: the all-taps stride-2 kernel
+    (2, 37, 24, 40, 3, 2),         # the same on an odd size with channel counts off its tiles
     (1, 52, 256, 512, 3, 2),
     (2, 52, 256, 128, 1, 1),
 ]

@@ -571,9 +571,18 @@ static long long wgrad_pixels(int B, int H, int W, int k, int stride) {
     return (long long)B * oh * ow;
 }
 
+static size_t wgrad_ws_need(int B, int H, int W, int Cin, int Cout, int k, int stride) {
+    size_t need = conv_wgrad_workspace_bytes(k, Cin, Cout, wgrad_pixels(B, H, W, k, stride));
+    if (k == 3 && stride == 2 && Cin % 8 == 0 && Cout % 8 == 0 && Cin <= 32) {
+        const size_t s2 = conv_wgrad_s2_workspace_bytes(B, H, W, Cin, Cout);
+        need = s2 > need ? s2 : need;
+    }
+    return need;
+}
+
 size_t ymx_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2)) return 0;
-    return conv_wgrad_workspace_bytes(k, Cin, Cout, wgrad_pixels(B, H, W, k, stride));
+    return wgrad_ws_need(B, H, W, Cin, Cout, k, stride);
 }
 
 int ymx_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw, int B, int H, int W, int Cin, int Cout, int k,
@@ -586,7 +595,7 @@ int ymx_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw
     if ((x_ld != 0 && (x_ld < Cin || x_ld % 8)) || (dz_ld != 0 && (dz_ld < Cout || dz_ld % 8))) return fail(YMX_EARG, "conv_wgrad: pixel strides must be multiples of 8 elements");
     if (!aligned16(x) || !aligned16(dz) || (((uintptr_t)dw) & 3)) return fail(YMX_EARG, "conv_wgrad: alignment");
     if ((long long)B * H * W * (x_ld ? x_ld : Cin) >= (1LL << 40)) return fail(YMX_EUNSUPPORTED, "conv_wgrad: input too large");
-    const size_t need = conv_wgrad_workspace_bytes(k, Cin, Cout, wgrad_pixels(B, H, W, k, stride));
+    const size_t need = wgrad_ws_need(B, H, W, Cin, Cout, k, stride);
     if (need && (!workspace || ws_bytes < need)) return fail(YMX_EWORKSPACE, "conv_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
     if (need && (((uintptr_t)workspace) & 3)) return fail(YMX_EARG, "conv_wgrad: workspace must be 4-byte aligned");
     return launch_conv_wgrad(x, x_ld, dz, dz_ld, dw, B, H, W, Cin, Cout, k, stride, workspace, (hipStream_t)stream);

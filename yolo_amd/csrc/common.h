@@ -263,6 +263,7 @@ int launch_bn_reduce(const void *u, const void *dy, void *dz, const float *scale
 int launch_bn_bwd_apply(const void *dz, const void *u, const float *a, const float *b, const float *c, void *du, long long P, int C,
                         int dtype, hipStream_t s);
 size_t conv_wgrad_workspace_bytes(int k, int Cin, int Cout, long long P);
+size_t conv_wgrad_s2_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int launch_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float *dw, int B, int H, int W, int Cin, int Cout, int k,
                       int stride, void *ws, hipStream_t s);
 const char *conv_wgrad_label(int B, int H, int W, int Cin, int Cout, int k, int stride);

@@ -989,6 +989,159 @@ static int wgrad_slab_splits(int Cin, int Cout, long long P, int W) {
 }
 
 
+// ---- weight gradient of 3x3 stride-2 layers: all nine taps from one staging of the input rows ------
+// The per-tap kernels give every tap its own workgroups, so x and dz cross the L2 nine times, and
+// with stride 2 each tap uses half of every 128-byte line it fetches: 32->64 @416 -> 208 moves
+// 6 GB through the L2 for 1.06 GB of operands.  Here a workgroup owns 32 input x 64 output
+// channels and all nine taps, and walks units of 64 consecutive output pixels of one output row.
+// Per unit it stages, PLANAR (one run of pixels per channel, as in conv_wgrad_first_kernel), the
+// three input rows the unit touches -- once per horizontal tap s, taking every second pixel, so
+// that XS[r][s][ci][j] = x[2 oh + r - 1][2 (ow0 + j) + s - 1][ci] -- and the dz row segment; both MFMA
+// operands are then aligned 16-byte LDS reads.  Two neighbouring output pixels are packed into one
+// 32-bit LDS store; the 16-byte chunks of a plane row are XOR-swizzled by the channel group so that
+// the lanes of a store instruction (four channel groups x consecutive pixel pairs) hit distinct banks.
+// Wave w keeps the accumulators of (tap, channel half) blocks w, w + 4, ... (4-5 of the 18) x four
+// output-channel blocks.  Units beyond a workgroup's share and pixels beyond the row are zeros.
+struct WgradS2Args {
+    const bf16_t *x, *dz;
+    float *partial;             // [gridDim.x][9][Cin][Cout]
+    int B, H, W, OH, OW, Cin, Cout, x_ld, dz_ld;
+    int nseg, units;            // 64-pixel segments per output row; B * OH * nseg
+};
+constexpr int WS2_SEG = 64, WS2_TCI = 32, WS2_TCO = 64;
+
+__global__ void __launch_bounds__(256)
+conv_wgrad_s2_kernel(const WgradS2Args a) {
+    __shared__ __attribute__((aligned(16))) char smem[(9 * WS2_TCI + WS2_TCO) * WS2_SEG * 2];
+    char *XS = smem;                                              // [3 r][3 s][32 ci][64 j] bf16, rows of 128 bytes
+    char *DZ = smem + 9 * WS2_TCI * WS2_SEG * 2;                  // [64 co][64 j]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ci0 = blockIdx.y * WS2_TCI, co0 = blockIdx.z * WS2_TCO;
+    f32x4_t acc[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // fragment addresses: operand row = lane & 15 of the block, pixels 8 * (lane >> 4) .. + 7 of a 32-pixel step
+    const int frow = lane & 15, kgrp = lane >> 4;
+    // The global loads of unit u + 1 are issued (into registers) before unit u is computed, so that their
+    // latency runs under the MFMAs and the LDS traffic of the current unit.
+    constexpr int NTASK = 3 * 3 * 4 * 32, NQ = (NTASK + 255) / 256;    // x tasks = (input row r, tap column s, channel group c8, pixel pair jp)
+    uint4 xa[NQ], xb[NQ], za, zb;
+    auto fetch = [&](int u) {
+        const int seg = u % a.nseg, rowid = u / a.nseg;
+        const int oh = rowid % a.OH, b = rowid / a.OH;
+        const int ow0 = seg * WS2_SEG;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = q * 256 + t;
+            xa[q] = make_uint4(0u, 0u, 0u, 0u);
+            xb[q] = xa[q];
+            if (i < NTASK) {
+                const int c8 = i & 3, jp = (i >> 2) & 31, rs = i >> 7, r = rs / 3, sx = rs - r * 3;
+                const int ih = 2 * oh + r - 1, iw = 2 * (ow0 + 2 * jp) + sx - 1, ci = ci0 + c8 * 8;
+                if (ih >= 0 && ih < a.H && ci < a.Cin) {
+                    const bf16_t *px = a.x + (((size_t)b * a.H + ih) * a.W) * a.x_ld + ci;
+                    if (iw >= 0 && iw < a.W && ow0 + 2 * jp < a.OW) xa[q] = *(const uint4 *)(px + (size_t)iw * a.x_ld);
+                    if (iw + 2 < a.W && ow0 + 2 * jp + 1 < a.OW) xb[q] = *(const uint4 *)(px + (size_t)(iw + 2) * a.x_ld);
+                }
+            }
+        }
+        {
+            const int c8 = t & 7, jp = t >> 3;                     // dz: 8 channel groups x 32 pixel pairs = one task per thread
+            za = make_uint4(0u, 0u, 0u, 0u);
+            zb = za;
+            const int co = co0 + c8 * 8, ow = ow0 + 2 * jp;
+            if (co < a.Cout) {
+                const bf16_t *pz = a.dz + (((size_t)b * a.OH + oh) * a.OW) * a.dz_ld + co;
+                if (ow < a.OW) za = *(const uint4 *)(pz + (size_t)ow * a.dz_ld);
+                if (ow + 1 < a.OW) zb = *(const uint4 *)(pz + (size_t)(ow + 1) * a.dz_ld);
+            }
+        }
+    };
+    // two neighbouring pixels of eight channels -> eight 32-bit words, one per channel plane
+    auto put = [&](char *base, const uint4 &va, const uint4 &vb) {
+        const uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            *(uint32_t *)(base + (2 * e) * 128) = (wa[e] & 0xffffu) | (wb[e] << 16);
+            *(uint32_t *)(base + (2 * e + 1) * 128) = (wa[e] >> 16) | (wb[e] & 0xffff0000u);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = q * 256 + t;
+            if (i < NTASK) {
+                const int c8 = i & 3, jp = (i >> 2) & 31, rs = i >> 7;
+                // dword jp of the plane row, its 16-byte chunk (jp >> 2) swizzled by the channel group
+                put(XS + (size_t)(rs * WS2_TCI + c8 * 8) * 128 + ((((jp >> 2) ^ c8) << 4) | ((jp & 3) << 2)), xa[q], xb[q]);
+            }
+        }
+        const int c8 = t & 7, jp = t >> 3;
+        put(DZ + (size_t)(c8 * 8) * 128 + ((((jp >> 2) ^ c8) << 4) | ((jp & 3) << 2)), za, zb);
+    };
+    if ((int)blockIdx.x < a.units) fetch(blockIdx.x);
+    for (int u = blockIdx.x; u < a.units; u += gridDim.x) {
+        __syncthreads();                                           // the previous unit's fragment reads are done
+        stash();
+        __syncthreads();
+        if (u + (int)gridDim.x < a.units) fetch(u + gridDim.x);
+#pragma unroll
+        for (int step = 0; step < WS2_SEG / 32; ++step) {
+            const int chunk = step * 4 + kgrp;
+            uint4 fb[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int co = nb * 16 + frow;
+                fb[nb] = *(const uint4 *)(DZ + co * 128 + ((chunk ^ (co >> 3)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int mb = wave + 4 * i;                       // (tap, channel half) block
+                if (mb < 18) {
+                    const int plane = mb * 16 + frow;              // = (tap * 32 + half * 16 + row)
+                    const uint4 fa = *(const uint4 *)(XS + plane * 128 + ((chunk ^ ((plane >> 3) & 3)) << 4));
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+                        acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa), __builtin_bit_cast(bf16x8_t, fb[nb]),
+                                                                             acc[i][nb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float *out = a.partial + (size_t)blockIdx.x * 9 * a.Cin * a.Cout;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int mb = wave + 4 * i;
+        if (mb < 18) {
+            const int tap = mb >> 1, half = mb & 1;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = ci0 + half * 16 + 4 * (lane >> 4) + r, co = co0 + nb * 16 + (lane & 15);
+                    if (ci < a.Cin && co < a.Cout) out[((size_t)tap * a.Cin + ci) * a.Cout + co] = acc[i][nb][r];
+                }
+        }
+    }
+}
+
+static bool wgrad_use_s2(int k, int stride, int Cin, int Cout) {
+    // the first stride-2 layer only (32 input channels, one channel tile): measured at batch 64, 32->64 @416->208
+    // 0.94 -> 0.54 ms, but 64->128 @208->104 0.32 -> 0.56 (two channel tiles restage the rows, and the planar
+    // staging's LDS stores, not memory, bound this kernel) and worse beyond; those stay on the per-tap kernels,
+    // whose tensors the L2 / Infinity Cache hold
+    return g_wgrad_variant == 0 && k == 3 && stride == 2 && Cin % 8 == 0 && Cout % 8 == 0 && Cin <= 32;
+}
+static int wgrad_s2_parts(int B, int OH, int OW, int Cin, int Cout) {
+    const long long tiles = (long long)((Cin + WS2_TCI - 1) / WS2_TCI) * ((Cout + WS2_TCO - 1) / WS2_TCO);
+    const long long units = (long long)B * OH * ((OW + WS2_SEG - 1) / WS2_SEG);
+    long long gx = (768 + tiles - 1) / tiles;                       // three workgroups per CU in all
+    if (gx > units) gx = units;
+    return (int)(gx < 1 ? 1 : gx);
+}
+
 static int wgrad_tci(int Cin, bool dma) { return dma ? (Cin > 128 ? 256 : (Cin > 64 ? 128 : 64)) : (Cin > 64 ? 128 : 64); }
 static bool wgrad_use_dma(long long x_bytes, long long dz_bytes) {
     return g_wgrad_variant != 1 && x_bytes < 0x7fffffffLL && dz_bytes < 0x7fffffffLL;
@@ -1013,6 +1166,11 @@ size_t conv_wgrad_workspace_bytes(int k, int Cin, int Cout, long long P) {
     }
     return splits > 1 ? (size_t)splits * k * k * Cin * Cout * 4 : 0;
 }
+// the stride-2 all-taps kernel's partial results (it is chosen by shape, so the caller's query must cover it)
+size_t conv_wgrad_s2_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    const int OH = (H + 1 - 3) / 2 + 1, OW = (W + 1 - 3) / 2 + 1;
+    return (size_t)wgrad_s2_parts(B, OH, OW, Cin, Cout) * 9 * Cin * Cout * 4;
+}
 
 // Which of the three weight-gradient kernels launch_conv_wgrad takes for dense tensors of this
 // shape under the calling thread's "wgrad_variant".
@@ -1020,6 +1178,7 @@ const char *conv_wgrad_label(int B, int H, int W, int Cin, int Cout, int k, int 
     const int OH = stride == 1 ? H : (H + 1 - k) / 2 + 1, OW = stride == 1 ? W : (W + 1 - k) / 2 + 1;
     const long long xb = wgrad_bytes((long long)B * H * W, Cin), zb = wgrad_bytes((long long)B * OH * OW, Cout);
     if (wgrad_use_slab(k, stride, W, xb, zb)) return "wgrad_slab";
+    if (wgrad_use_s2(k, stride, Cin, Cout)) return "wgrad_s2";
     return wgrad_use_dma(xb, zb) ? "wgrad_dma" : "wgrad_reg";
 }
 
@@ -1058,6 +1217,19 @@ int launch_conv_wgrad(const void *x, int x_ld, const void *dz, int dz_ld, float 
         if (rc || splits == 1) return rc;
         const size_t n = (size_t)9 * Cin * Cout;
         launch_sum_partials((const float *)ws, dw, n, splits, s);
+        return check_launch("conv_wgrad_reduce");
+    }
+    if (wgrad_use_s2(k, stride, Cin, Cout)) {
+        WgradS2Args sa;
+        sa.x = a.x; sa.dz = a.dz; sa.partial = (float *)ws;
+        sa.B = B; sa.H = H; sa.W = W; sa.OH = a.OH; sa.OW = a.OW; sa.Cin = Cin; sa.Cout = Cout; sa.x_ld = a.x_ld; sa.dz_ld = a.dz_ld;
+        sa.nseg = (a.OW + WS2_SEG - 1) / WS2_SEG;
+        sa.units = B * a.OH * sa.nseg;
+        const int parts = wgrad_s2_parts(B, a.OH, a.OW, Cin, Cout);
+        hipLaunchKernelGGL(conv_wgrad_s2_kernel, dim3(parts, (Cin + WS2_TCI - 1) / WS2_TCI, (Cout + WS2_TCO - 1) / WS2_TCO), dim3(256), 0, s, sa);
+        int rc = check_launch("conv_wgrad_s2");
+        if (rc) return rc;
+        launch_sum_partials((const float *)ws, dw, (size_t)9 * Cin * Cout, parts, s);
         return check_launch("conv_wgrad_reduce");
     }
     const bool dma = wgrad_use_dma(xb, zb);
