@@ -208,7 +208,7 @@ def test_upsample_concat_gradient():
     from yolo_amd import training as T
     from yolo_amd.layers import upsample2x_concat
     g = torch.Generator().manual_seed(9)
-    for (B, H, W, c1, c2) in ((2, 5, 7, 16, 24), (1, 13, 13, 0, 8), (1, 1, 1, 8, 8)):
+    for (B, H, W, c1, c2) in ((2, 5, 7, 16, 24), (1, 13, 13, 0, 8), (1, 1, 1, 8, 8), (2, 26, 26, 256, 128)):
         x = N.bf16_round(torch.randn(B, H, W, c2, generator=g))
         skip = N.bf16_round(torch.randn(B, 2 * H, 2 * W, c1, generator=g)) if c1 else None
         G = N.bf16_round(torch.randn(B, 2 * H, 2 * W, c1 + c2, generator=g))
