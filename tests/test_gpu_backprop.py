@@ -97,6 +97,18 @@ def test_conv_block_gradients(case):
             T.trace = None
         assert _scaled_err(layer.kernel.grad.cpu(), po["kernel"].grad) < 1e-2
         assert _scaled_err(layer.kernel.grad.cpu(), g_auto.cpu()) < 1e-5          # same products, another summation order
+    # the weight gradient on a second stream beside the input gradient: the same bits
+    layer.kernel.grad = None
+    try:
+        T.overlap_wgrad = True
+        xs = xg.detach().requires_grad_(True)
+        with T.backprop():
+            y3 = layer(xs, residual=None if scg is None else scg.detach())
+        (y3.float() * G.to(DEV)).sum().backward()
+    finally:
+        T.overlap_wgrad = False
+    torch.cuda.synchronize()
+    assert torch.equal(layer.kernel.grad, g_auto) and torch.equal(xs.grad, xg.grad)
     # outside the context nothing is recorded and the fused inference kernels run
     y_inf = layer(xg.detach(), residual=None if scg is None else scg.detach())
     assert not y_inf.requires_grad

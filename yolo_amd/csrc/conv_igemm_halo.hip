@@ -342,9 +342,10 @@ int conv_halo_tile_pixels(const ConvArgs &a) {
     const long long ntq = (a.Cout + 255) / 256;
     const long long r256 = (((long long)a.P + 255) / 256 * ntq + 255) / 256;
     const long long r192 = (((long long)a.P + 191) / 192 * ntq + 255) / 256;
-    // (layers of 512 input channels, 72 K tiles: the fixed costs of a tile weigh less and a 192-pixel round
-    // measures 0.70-0.73 of a 256-pixel one)
-    const double f192 = a.Cin >= 512 ? 0.72 : 0.82;
+    // (layers of 512 and more input channels, 72+ K tiles, in launches of a few rounds: the fixed costs of a
+    // tile weigh less and a 192-pixel round measures 0.70-0.73 of a 256-pixel one; with more rounds the
+    // workgroups drift apart, whole rounds stop being the unit, and 256-pixel tiles measure faster again)
+    const double f192 = (a.Cin >= 512 && r256 <= 4) ? 0.72 : 0.82;
     return (double)r192 * f192 < (double)r256 * 0.97 ? 192 : 256;
 }
 
