@@ -514,6 +514,15 @@ def test_gradient_buckets_receive_the_block_gradients_in_place():
             assert torch.allclose(m.kernel.grad, want[i] + 0.001 * m.kernel.detach(), rtol=1e-6, atol=1e-9)
             j = [id(p) for p in params].index(id(m.bias))
             assert torch.equal(m.bias.grad, want[j])
+    # back to plain gradients: the blocks hand them to autograd again, the buckets are left alone
+    snapshot = [bk.clone() for bk in gb.buckets]
+    for p in params:
+        p.grad = None
+    run()
+    assert all(torch.equal(p.grad, w) for p, w in zip(params, want))
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(gb.buckets, snapshot))
+    gb.close()
+    assert not any(hasattr(p, "_grad_bucket") for p in params)
     pen = float(reg.penalty())
     assert abs(pen - 0.0005 * sum(float(k.detach().double().square().sum()) for k in reg.kernels)) < 1e-6 * pen
 

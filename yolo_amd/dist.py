@@ -214,3 +214,13 @@ class GradientBuckets(object):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+    def close(self):
+        """Detach from the parameters: hooks removed, gradients handed back as ordinary tensors
+        (copies of the current values)."""
+        self.remove_hooks()
+        for p in self.params:
+            if getattr(p, "_grad_bucket", (None,))[0] is self:
+                del p._grad_bucket
+                if p.grad is not None:
+                    p.grad = p.grad.clone()

@@ -117,8 +117,13 @@ def _side_stream(device):
 
 
 def _slot(param):
-    """(GradientBuckets, view of the parameter's place in its bucket) or None."""
-    return getattr(param, "_grad_bucket", None)
+    """(GradientBuckets, view of the parameter's place in its bucket) or None.  Only while the
+    parameter's .grad still IS that view: a caller who went back to plain gradients (``p.grad =
+    None``) gets them from autograd as usual."""
+    slot = getattr(param, "_grad_bucket", None)
+    if slot is None or param.grad is None or param.grad.data_ptr() != slot[1].data_ptr():
+        return None
+    return slot
 
 
 def _empty(shape, like, dtype=None):
