@@ -496,3 +496,31 @@ def test_library_code_has_no_packed_fma_of_the_hazardous_form():
     found, functions = isa_lint.scan(_lib.LIB_PATH)
     assert functions >= 100, functions          # the disassembly really covered the kernels
     assert found == [], found
+
+
+def test_l2_regulariser_and_bucket_close_on_cpu():
+    """training.L2Regulariser is plain tensor arithmetic (runs anywhere): the gradient gains
+    2 * c * kernel, biases are left alone; GradientBuckets.close() hands plain gradients back."""
+    from yolo_amd import training as T, dist as D
+    from yolo_amd.layers import YOLOConv
+    net = torch.nn.ModuleList([YOLOConv((3, 3, 8), in_channels=4), YOLOConv((1, 1, 6), in_channels=8)])
+    reg = T.L2Regulariser(net, coefficient=0.0005)
+    assert len(reg.kernels) == 2
+    for p in net.parameters():
+        p.grad = torch.ones_like(p)
+    reg.add_gradients_()
+    for m in net:
+        assert torch.allclose(m.kernel.grad, 1.0 + 0.001 * m.kernel.detach())
+        assert torch.equal(m.bias.grad, torch.ones_like(m.bias))
+    want = 0.0005 * sum(float((m.kernel.detach().double() ** 2).sum()) for m in net)
+    assert abs(float(reg.penalty()) - want) < 1e-12 + 1e-6 * want
+    params = list(net.parameters())
+    gb = D.GradientBuckets(params, bucket_bytes=256)
+    assert all(p.grad.data_ptr() == p._grad_bucket[1].data_ptr() for p in params)
+    assert T._slot(params[0]) is not None
+    params[0].grad = None
+    assert T._slot(params[0]) is None            # a caller who went back to plain gradients gets them from autograd
+    gb.close()
+    assert not any(hasattr(p, "_grad_bucket") for p in params)
+    with pytest.raises(Exception):
+        T.batch_norm_act(torch.nn.Module(), torch.zeros(1, 2, 2, 8))    # CPU tensors: no fallback
