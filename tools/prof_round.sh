@@ -29,9 +29,10 @@ cp $(find $O/s_trace -name '*kernel_stats.csv' | head -1) $O/${TAG}_stress_kerne
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/s_fetch -- python3 $SARGS > $O/s_fetch.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/s_write -- python3 $SARGS > $O/s_write.log 2>&1
 python3 tools/pmc_summary.py $(find $O/s_fetch -name '*counter_collection.csv' | head -1) $(find $O/s_write -name '*counter_collection.csv' | head -1) 2 > $O/${TAG}_pmc_traffic_stress.json
-# training step: kernel trace (weight gradients on the main stream so that per-kernel times add up)
-OVERLAP=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/tr -o tr -- python3 tools/train_step_time.py 64 416 4 > $O/tr.log 2>&1
-(echo "rocprofv3 --kernel-trace of OVERLAP=0 tools/train_step_time.py 64 416 4 (one MI355X; 5 steps incl. the first)
+# training step: kernel trace (everything on one stream, so per-kernel times add up), then the same step without the profiler
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/tr -o tr -- python3 tools/train_step_time.py 64 416 4 > $O/tr.log 2>&1
+timeout -k 10 200 python3 tools/train_step_time.py 64 416 6 > $O/tr_plain.log 2>&1
+(echo "rocprofv3 --kernel-trace of tools/train_step_time.py 64 416 4 (one MI355X; 5 steps incl. the first); without the profiler: $(grep 'train step' $O/tr_plain.log | tail -1)"; echo "columns: kernel, launches per step, ms per step"; python3 tools/trace_summary.py $(find $O/tr -name 'tr_results.db' | head -1) 5) > $O/${TAG}_train_kernel_trace_summary.txt
 # drop the bulky raw outputs, keep the summaries
 rm -rf $O/t_off $O/p_fetch $O/p_write $O/p_mfma $O/s_trace $O/s_fetch $O/s_write $O/tr
 ls -la $O
