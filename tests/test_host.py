@@ -524,3 +524,38 @@ def test_l2_regulariser_and_bucket_close_on_cpu():
     assert not any(hasattr(p, "_grad_bucket") for p in params)
     with pytest.raises(Exception):
         T.batch_norm_act(torch.nn.Module(), torch.zeros(1, 2, 2, 8))    # CPU tensors: no fallback
+
+
+def test_training_entry_points_validate_without_gpu():
+    """The training-side entry points reject bad shapes before any launch (CPU-only box)."""
+    from yolo_amd import _lib
+    L = _lib.lib()
+    one = ctypes.c_void_p(256)
+    # depth-to-space input gradient: dz channels and Cin in multiples of 8, output map 2 OH (+1) on a side
+    assert L.ymx_conv2d_dgrad_s2(one, one, one, 1, 4, 4, 12, 8, 8, 8, None) == -1 and b"multiples of 8" in L.ymx_last_error()
+    assert L.ymx_conv2d_dgrad_s2(one, one, one, 1, 4, 4, 16, 12, 8, 8, None) == -1
+    assert L.ymx_conv2d_dgrad_s2(one, one, one, 1, 4, 4, 16, 8, 12, 8, None) == -1 and b"does not match" in L.ymx_last_error()
+    # forward with two outputs: bf16 with an activation
+    assert L.ymx_conv2d_fused_z(one, one, None, None, None, one, one, 1, 8, 8, 8, 8, 3, 1, 0, _lib.BF16, None) == -1
+    assert L.ymx_conv2d_fused_z(one, one, None, None, None, one, None, 1, 8, 8, 8, 8, 3, 1, 2, _lib.BF16, None) == -1
+    # pair pack: stride 2 only for 3x3 bf16; MFMA channel counts
+    assert L.ymx_pack_weights_pair(one, one, one, 1, 8, 8, 8, 2, _lib.BF16, None) == -1
+    assert L.ymx_pack_weights_pair(one, one, one, 3, 3, 8, 8, 1, _lib.BF16, None) == -2
+    assert L.ymx_pack_weights_dgrad_s2(one, one, 12, 8, 8, _lib.BF16, None) == -1
+    # first-layer weight gradient: at most 3 input channels, 64 output channels in multiples of 8
+    assert L.ymx_conv_wgrad_first_workspace_bytes(2, 64, 64, 3, 32) == min(2 * 64, 768) * 4 * 27 * 32 * 4
+    assert L.ymx_conv_wgrad_first_workspace_bytes(2, 64, 64, 8, 32) == 0
+    assert L.ymx_conv_wgrad_first_workspace_bytes(2, 64, 64, 3, 36) == 0
+    assert L.ymx_conv_wgrad_first(one, _lib.F32, one, 0, one, 2, 64, 64, 4, 32, one, 1 << 30, None) == -2
+    assert L.ymx_conv_wgrad_first(one, _lib.F32, one, 0, one, 2, 64, 64, 3, 32, one, 16, None) == -3
+    # batch-norm pieces and the SPP pair: null pointers, sizes, workspace
+    assert L.ymx_bn_workspace_bytes(1000, 64) == 2 * 2 * 64 * 4
+    assert L.ymx_bn_stats(one, 1000, 64, _lib.BF16, one, one, 8, None) == -1 and b"workspace" in L.ymx_last_error()
+    assert L.ymx_bn_act_forward(one, None, one, None, one, 10, 8, 2, _lib.BF16, None) == -1
+    assert L.ymx_bn_backward_apply(one, one, one, one, one, one, 0, 8, _lib.BF16, None) == -1
+    assert L.ymx_spp_concat_train(one, one, None, 1, 13, 13, 8, _lib.BF16, None) == -1
+    assert L.ymx_spp_concat_backward(one, one, one, 1, 13, 13, 8, 7, None) == -1
+    # the weight-gradient label covers the stride-2 all-taps kernel's shapes
+    assert L.ymx_conv_wgrad_kernel_label(64, 416, 416, 32, 64, 3, 2) == b"wgrad_s2"
+    assert L.ymx_conv_wgrad_kernel_label(64, 208, 208, 64, 128, 3, 2) == b"wgrad_dma"
+    assert L.ymx_conv_wgrad_kernel_label(64, 52, 52, 512, 1024, 3, 1) == b"wgrad_slab"

@@ -105,6 +105,7 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
     if (d2s) {
         if (stride != 1 || act != YMX_ACT_NONE || residual || dtype != YMX_BF16 || out_dtype != YMX_BF16 || y_ld > 0 || z)
             return fail(YMX_EARG, "conv2d: the depth-to-space form is bf16, stride 1, linear, without shortcut");
+        if (!conv_uses_mfma(Cin, dtype)) return fail(YMX_EARG, "conv2d: the depth-to-space form needs input channels in multiples of 8, got %d", Cin);
         if (d2s[2] <= 0 || d2s[2] % 8 || Cout != 4 * d2s[2] || d2s[0] < 2 * H || d2s[0] > 2 * H + 1 || d2s[1] < 2 * W || d2s[1] > 2 * W + 1)
             return fail(YMX_EARG, "conv2d: depth-to-space output [%d,%d,%d] does not match %d x %d x %d", d2s[0], d2s[1], d2s[2], H, W, Cout);
         a.pad = 0; a.OH = H; a.OW = W;
