@@ -74,6 +74,12 @@ def main():
         d = d / 100.0
         print("  %-24s median %7.2f  p10 %7.2f  p90 %7.2f us" % (names[i], np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
     print("  kernel span %.1f us" % ((s[:, 4].max() - s[:, 0].min()) / 100.0))
+    # inside "sort" (last selection round of the workgroup): selection histogram + compaction, the sort, the greedy pass
+    ok = s[(s[:, 5] > s[:, 2]) & (s[:, 7] >= s[:, 6])]
+    if ok.shape[0]:
+        for name, i0, i1 in (("  select (min/max, histogram, cut, compact)", 2, 5), ("  sort of the selection", 5, 6), ("  greedy pass", 6, 7), ("  after it", 7, 3)):
+            d = (ok[:, i1] - ok[:, i0]) / 100.0
+            print("  %-44s median %7.2f  p10 %7.2f  p90 %7.2f us" % (name, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
 
 
 if __name__ == "__main__":

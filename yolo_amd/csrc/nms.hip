@@ -478,6 +478,7 @@ nms_class_kernel(const NmsArgs a) {
                     }
                 }
                 __syncthreads();
+                NSTAMP(5);
                 const int nsel = s_cnt2;
                 const u64 *sorted;
                 if (nsel <= 500) {
@@ -494,7 +495,9 @@ nms_class_kernel(const NmsArgs a) {
                     sorted = sel;
                 }
                 __syncthreads();
+                NSTAMP(6);
                 greedy(sorted, nsel);
+                NSTAMP(7);
                 if (t == 0) { s_last = kmin; s_last2 = sorted[nsel - 1]; }
                 __syncthreads();
                 if (s_nkept >= PC || cb2 == 0) break;      // done, or every key of the buffer visited
