@@ -438,10 +438,28 @@ int ymx_letterbox(const void *images, int in_dtype, int B, int H, int W, void *o
  * classes [B,max_boxes] fp32, as ymx_nms_combined writes them) are outlined in order, in
  * colors[class] (device, [C][3] 8-bit), `thickness` pixels wide (values below 1 draw 1),
  * on images [B,H,W,3] 8-bit, in place.  Corners are (int)(coordinate * size); a later box
- * paints over an earlier one.  Text labels (cv2.putText) are not drawn. */
+ * paints over an earlier one.  No text labels: ymx_draw_boxes_labeled draws those. */
 int ymx_draw_boxes(unsigned char *images, int B, int H, int W, const float *boxes,
                    const float *classes, const int *valid, int max_boxes,
                    const unsigned char *colors, int C, int thickness, void *stream);
+
+/* The same with the text labels of draw_bbox (utils.py:233-240, the show_label branch):
+ * labels [B,max_boxes,label_bytes] (device) holds one string per detection, zero-padded
+ * (the reference's '%s: %.2f' % (class name, score), formatted by the caller; a string of
+ * label_bytes characters needs no terminator, an empty one draws no label).  After its
+ * outline each detection gets a rectangle filled with its class colour from (x1, y1) to
+ * (x1 + text_width, y1 - text_height - 3), corners included, and the text in black with its
+ * lowest row at y1 - 3.  The typeface is a built-in 5x7 bitmap in a 6-pixel cell, each font
+ * pixel text_scale x text_scale image pixels (1..16): text_width = 6 * text_scale * length,
+ * text_height = 7 * text_scale.  OpenCV's Hershey strokes and anti-aliasing
+ * (cv2.putText, FONT_HERSHEY_SIMPLEX, LINE_AA) are not reproduced: the placement, colours
+ * and painting order are the reference's, the glyph shapes are this library's.
+ * label_bytes 1..256. */
+int ymx_draw_boxes_labeled(unsigned char *images, int B, int H, int W, const float *boxes,
+                           const float *classes, const int *valid, int max_boxes,
+                           const unsigned char *colors, int C, int thickness,
+                           const unsigned char *labels, int label_bytes, int text_scale,
+                           void *stream);
 
 /* ---- label assignment ---------------------------------------------------------
  * Replaces WIDERDataset.preprocess_true_boxes (dataset.py:387-482) for a batch: every

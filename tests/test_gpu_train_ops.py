@@ -231,6 +231,41 @@ def test_draw_boxes_vs_oracle(thickness):
     assert (want[1] == imgs[1]).all() and (want[0] != imgs[0]).any()
 
 
+@pytest.mark.parametrize("scale", [1, 2, 3])
+def test_draw_boxes_with_labels_vs_oracle(scale):
+    """Labels (utils.py:233-240): filled rectangle then black text after each outline, later
+    detections over earlier ones, clipped at the image border, exact against the oracle."""
+    from oracle import image_np as IM
+    from yolo_amd import utils as U
+    rng = np.random.default_rng(11 + scale)
+    B, H, W, M, C = 3, 120, 160, 10, 6
+    imgs = rng.integers(0, 256, (B, H, W, 3)).astype(np.uint8)
+    lo = rng.uniform(0, 0.7, (B, M, 2)).astype(np.float32)
+    hi = np.minimum(lo + rng.uniform(0.02, 0.5, (B, M, 2)).astype(np.float32), 1.0).astype(np.float32)
+    boxes = np.concatenate([lo, hi], -1)
+    boxes[0, 0] = [0.0, 0.0, 0.5, 0.5]                         # label above the top edge: clipped away
+    boxes[0, 1] = [0.3, 0.9, 0.6, 1.0]                         # label runs off the right edge
+    boxes[0, 3] = boxes[0, 2]                                  # same corner: the later label wins
+    classes = rng.integers(0, C, (B, M)).astype(np.float32)
+    classes[2, 1] = C                                          # skipped, label and all
+    valid = np.array([M, 0, 6], np.int32)
+    names = ["face", "Dog_2", "x", "a~b{c}", "p\xe9", "0123456789"]
+    scores = rng.uniform(0, 1, (B, M)).astype(np.float32)
+    labels = [[IM.label_text(names[int(c) % C], sc) for c, sc in zip(classes[b][:valid[b]], scores[b])] for b in range(B)]
+    labels[0][4] = ""                                          # no label for this one
+    labels[2][2] = "W" * 60                                    # cut at LABEL_BYTES by the host side
+    want_labels = [[t[:U.LABEL_BYTES] for t in row] for row in labels]
+    want = np.stack([IM.draw_boxes(imgs[b], boxes[b], classes[b], valid[b], C, 2, want_labels[b] + [""] * M, scale)
+                     for b in range(B)])
+    d = torch.from_numpy(imgs).to(DEV)
+    U.draw_boxes(d, torch.from_numpy(boxes).to(DEV), torch.from_numpy(classes).to(DEV), torch.from_numpy(valid).to(DEV),
+                 C, 2, labels=labels, text_scale=scale)
+    np.testing.assert_array_equal(d.cpu().numpy(), want)
+    plain = np.stack([IM.draw_boxes(imgs[b], boxes[b], classes[b], valid[b], C, 2) for b in range(B)])
+    assert (want != plain).any() and (want[1] == imgs[1]).all()
+    assert (want == 0).all(-1).sum() > (plain == 0).all(-1).sum()      # black text pixels appeared
+
+
 def test_draw_bbox_end_to_end():
     """draw_bbox = bbox_nms on the model output + outlines (utils.py:197-242): the drawn images
     equal the oracle's drawing of the detections the GPU NMS returns."""
@@ -241,12 +276,24 @@ def test_draw_bbox_end_to_end():
     heads = [(torch.randn(B, s, s, 3 * (5 + C), generator=g) * 2).to(DEV) for s in (8, 4, 2)]
     imgs = torch.zeros(B, 64, 64, 3, dtype=torch.uint8, device=DEV)
     det = U.bbox_nms(heads, 64, num_classes=C)
-    outs = U.draw_bbox(imgs, heads, 64, C)
+    outs = U.draw_bbox(imgs, heads, 64, C, show_label=False)
     assert len(outs) == B and int(det[3].sum()) > 0
     for b in range(B):
         want = IM.draw_boxes(np.zeros((64, 64, 3), np.uint8), det[0][b].cpu().numpy(), det[2][b].cpu().numpy(),
                              int(det[3][b]), C, int(0.6 * 128 / 600))
         np.testing.assert_array_equal(outs[b].cpu().numpy(), want)
+    # with captions '<name>: <score>' (utils.py:234), names defaulting to the class indices
+    names = ["ant", "bee", "cat"]
+    for cls_names, shown in ((None, ["0", "1", "2"]), (names, names)):
+        imgs2 = torch.full((B, 64, 64, 3), 200, dtype=torch.uint8, device=DEV)
+        outs2 = U.draw_bbox(imgs2, heads, 64, C, classes=cls_names, text_scale=1)
+        for b in range(B):
+            n = int(det[3][b])
+            cl, sc = det[2][b].cpu().numpy(), det[1][b].float().cpu().numpy()
+            labels = [IM.label_text(shown[int(cl[j])], sc[j]) for j in range(n)]
+            want = IM.draw_boxes(np.full((64, 64, 3), 200, np.uint8), det[0][b].cpu().numpy(), cl, n, C,
+                                 int(0.6 * 128 / 600), labels, 1)
+            np.testing.assert_array_equal(outs2[b].cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("S,C,scale,B", [(13, 80, 2, 3), (26, 80, 1, 2), (52, 3, 0, 2), (7, 1, 1, 2)])

@@ -79,6 +79,29 @@ def test_argument_validation_without_gpu():
     assert L.ymx_set_option(b"wgrad_variant", 2) == 0 and L.ymx_set_option(b"wgrad_variant", 0) == 0
 
 
+def test_label_encoding_and_labeled_draw_validation():
+    """Host half of the captions of draw_bbox (utils.py:234): string formatting, the
+    zero-padded byte table the library takes, and the entry point's argument checks."""
+    import numpy as np
+    from yolo_amd import _lib, utils as U
+    assert U.label_text("face", np.float32(0.125)) == "face: 0.12" and U.label_text("7", 1.0) == "7: 1.00"
+    tab = U.encode_labels([["ab", None, "\u20ac\xe9"], []], 4, label_bytes=3)
+    assert tab.shape == (2, 4, 3) and tab.dtype == np.uint8
+    assert tab[0, 0].tolist() == [97, 98, 0] and tab[0, 1].tolist() == [0, 0, 0] and tab[0, 2].tolist() == [127, 0xE9, 0]
+    assert not tab[1].any()
+    assert U.encode_labels([["abcdef"]], 1, label_bytes=4)[0, 0].tolist() == [97, 98, 99, 100]      # cut, no terminator
+    with pytest.raises(ValueError, match="detection slots"):
+        U.encode_labels([["a", "b"]], 1)
+    L = _lib.lib()
+    one = ctypes.c_void_p(16)
+    assert L.ymx_draw_boxes_labeled(one, 1, 8, 8, one, one, one, 4, one, 3, 1, None, 16, 2, None) == -1 and b"null" in L.ymx_last_error()
+    assert L.ymx_draw_boxes_labeled(one, 1, 8, 8, one, one, one, 4, one, 3, 1, one, 0, 2, None) == -1 and b"label_bytes" in L.ymx_last_error()
+    assert L.ymx_draw_boxes_labeled(one, 1, 8, 8, one, one, one, 4, one, 3, 1, one, 257, 2, None) == -1
+    assert L.ymx_draw_boxes_labeled(one, 1, 8, 8, one, one, one, 4, one, 3, 1, one, 16, 0, None) == -1 and b"text_scale" in L.ymx_last_error()
+    assert L.ymx_draw_boxes_labeled(one, 1, 8, 8, one, one, one, 4, one, 3, 1, one, 16, 17, None) == -1
+    assert L.ymx_draw_boxes_labeled(one, 0, 8, 8, one, one, one, 4, one, 3, 1, one, 16, 2, None) == -1
+
+
 def test_module_interface_matches_reference():
     import yolo_amd
     from yolo_amd import layers, backbones, detectors

@@ -453,6 +453,39 @@ def test_draw_boxes_known_answer():
     assert (thick[1:4, 1:8] != 0).any(axis=-1).all() and (thick[4, 4] == 0).all()
 
 
+def test_draw_labels_known_answer():
+    """The label of utils.py:233-240 with the 5x7 typeface: rectangle extent, text rows and
+    one glyph spelled out pixel by pixel."""
+    from oracle import image_np as IM
+    img = np.full((40, 60, 3), 9, np.uint8)
+    boxes = np.array([[0.5, 0.25, 0.9, 0.75]], np.float32)          # y1 = 20, x1 = 15
+    out = IM.draw_boxes(img, boxes, np.array([0.0]), 1, 4, 1, ["T1"], 1)
+    red = np.array([255, 0, 0], np.uint8)
+    # rectangle: x 15 .. 15 + 12, y 20 - 7 - 3 .. 20, both inclusive
+    region = out[10:21, 15:28]
+    assert ((region == red).all(-1) | (region == 0).all(-1)).all()
+    assert (out[9, 15:28] == 9).all() and (out[10:20, 28] == 9).all() and (out[10:20, 14] == 9).all()
+    black = (out == 0).all(-1)
+    ys, xs = np.nonzero(black)
+    assert ys.min() == 11 and ys.max() == 17                        # seven rows ending at y1 - 3
+    # 'T': top bar over five columns and a centre stem
+    assert black[11, 15:20].all() and black[12:18, 17].all() and not black[12:18, 15].any()
+    # '1' in the next cell (x 21..25): stem in its middle column
+    assert black[11:18, 23].all() and not black[:, 20].any() and not black[:, 26:].any()
+    # scale 2 doubles every font pixel
+    out2 = IM.draw_boxes(np.full((60, 80, 3), 9, np.uint8), np.array([[0.5, 0.25, 0.9, 0.75]], np.float32),
+                         np.array([0.0]), 1, 4, 1, ["T"], 2)
+    b2 = (out2 == 0).all(-1)
+    y1, x1 = 30, 20
+    assert b2[y1 - 2 - 14:y1 - 2 - 12, x1:x1 + 10].all() and b2[y1 - 16:y1 - 2, x1 + 4:x1 + 6].all()
+    assert IM.label_text("face", np.float32(0.987)) == "face: 0.99"
+    # no label when the string is empty; unknown codes draw the hollow box
+    assert (IM.draw_boxes(img, boxes, np.array([0.0]), 1, 4, 1, [""], 1) ==
+            IM.draw_boxes(img, boxes, np.array([0.0]), 1, 4, 1)).all()
+    hollow = (IM.draw_boxes(img, boxes, np.array([0.0]), 1, 4, 1, ["\x01"], 1) == 0).all(-1)
+    assert hollow[11:18, 15].all() and hollow[11:18, 19].all() and hollow[11, 15:20].all() and not hollow[13, 16:19].any()
+
+
 def test_loss_torch_restatement_matches_numpy_and_finite_differences():
     """The torch restatement used for gradients gives the numpy restatement's loss values, and
     its automatic gradient agrees with central finite differences of its own forward."""

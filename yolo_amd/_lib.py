@@ -86,6 +86,7 @@ SIGNATURES = {
     "ymx_upsample2x_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ymx_letterbox": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "ymx_draw_boxes": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "ymx_draw_boxes_labeled": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     "ymx_yolo_loss_workspace_bytes": (_sz, [_i, _i]),
     "ymx_yolo_loss": (_i, [_vp, _i, _vp, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _i, _i, _i, _i, _f, _f, ctypes.POINTER(_f), _f, _vp, _vp, _vp, _sz, _vp]),
     "ymx_assign_labels": (_i, [_vp, _vp, _i, _i, _i, _i, ctypes.POINTER(_f), ctypes.POINTER(_f), ctypes.POINTER(_vp),

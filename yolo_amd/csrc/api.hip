@@ -699,7 +699,19 @@ int ymx_draw_boxes(unsigned char *images, int B, int H, int W, const float *boxe
                    int max_boxes, const unsigned char *colors, int C, int thickness, void *stream) {
     if (!images || !boxes || !classes || !valid || !colors) return fail(YMX_EARG, "draw_boxes: null pointer");
     if (B <= 0 || H <= 0 || W <= 0 || max_boxes <= 0 || C <= 0) return fail(YMX_EARG, "draw_boxes: non-positive size");
-    return launch_draw_boxes(images, B, H, W, boxes, classes, valid, max_boxes, colors, C, thickness, (hipStream_t)stream);
+    return launch_draw_boxes(images, B, H, W, boxes, classes, valid, max_boxes, colors, C, thickness, nullptr, 0, 1,
+                             (hipStream_t)stream);
+}
+
+int ymx_draw_boxes_labeled(unsigned char *images, int B, int H, int W, const float *boxes, const float *classes,
+                           const int *valid, int max_boxes, const unsigned char *colors, int C, int thickness,
+                           const unsigned char *labels, int label_bytes, int text_scale, void *stream) {
+    if (!images || !boxes || !classes || !valid || !colors || !labels) return fail(YMX_EARG, "draw_boxes_labeled: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || max_boxes <= 0 || C <= 0) return fail(YMX_EARG, "draw_boxes_labeled: non-positive size");
+    if (label_bytes < 1 || label_bytes > 256) return fail(YMX_EARG, "draw_boxes_labeled: label_bytes=%d (1..256)", label_bytes);
+    if (text_scale < 1 || text_scale > 16) return fail(YMX_EARG, "draw_boxes_labeled: text_scale=%d (1..16)", text_scale);
+    return launch_draw_boxes(images, B, H, W, boxes, classes, valid, max_boxes, colors, C, thickness, labels, label_bytes,
+                             text_scale, (hipStream_t)stream);
 }
 
 size_t ymx_yolo_loss_workspace_bytes(int B, int S) { return yolo_loss_workspace_bytes(B, S); }

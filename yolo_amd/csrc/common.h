@@ -250,7 +250,8 @@ int launch_spp_train(const void *x, void *y, unsigned char *arg, int B, int H, i
 int launch_spp_bwd(const void *dy, const unsigned char *arg, void *dx, int B, int H, int W, int C, int dtype, hipStream_t s);
 int launch_letterbox(const void *src, int in_u8, int B, int H, int W, void *dst, int out_bf16, int T, int literal, hipStream_t s);
 int launch_draw_boxes(unsigned char *img, int B, int H, int W, const float *boxes, const float *classes, const int *valid, int M,
-                      const unsigned char *colors, int C, int thick, hipStream_t s);
+                      const unsigned char *colors, int C, int thick, const unsigned char *labels, int L, int scale,
+                      hipStream_t s);
 int launch_act(const void *z, const void *other, void *y, size_t n, int act, int dtype, int mode, hipStream_t s);
 size_t bias_grad_workspace_bytes(long long P, int C);
 bool act_bwd_bias_supported(long long P, int C, int act, int dtype);

@@ -103,26 +103,60 @@ int launch_letterbox(const void *src, int in_u8, int B, int H, int W, void *dst,
     return check_launch("letterbox");
 }
 
-// ---- box outlines --------------------------------------------------------------------------
-// One thread per pixel; the boxes of the image are visited in order and the last outline that
-// covers the pixel wins, which is what drawing them one after another gives.  Corners are
+// ---- box outlines and labels ----------------------------------------------------------------
+// One thread per pixel; the boxes of the image are visited in order and the last thing drawn
+// over the pixel wins, which is what drawing them one after another gives.  Corners are
 // (int)(coordinate * size) as utils.py:220-223; an outline of thickness t covers, on each of
 // the four sides, t pixel lines around the side ((t - 1) / 2 towards lower coordinates, t / 2
 // towards higher ones), over the whole extent of the box
 // enlarged by the same amounts.  Detections with a class outside [0, C] are skipped
 // (utils.py:218 tests "> num_classes"; class == C has no colour and is skipped here too).
+//
+// Labels (utils.py:233-240): after its outline, a detection with a non-empty label gets a
+// rectangle filled with the class colour from the corner c1 = (x1, y1) to
+// (x1 + text_width, y1 - text_height - 3), both corners included, and the text in black on
+// it with its lowest pixel row at y1 - 3 (cv2.putText's origin (x1, y1 - 2) is the baseline,
+// drawn below the glyph bodies).  The typeface is this library's own: a 5x7 bitmap in a 6-wide
+// cell, every font pixel a scale x scale square, so text_width = 6 * scale * length and
+// text_height = 7 * scale (OpenCV's Hershey strokes are not reproduced).
+// Codes outside 32..126 show as a hollow box.
+__constant__ unsigned char kFont5x7[95][5] = {   // column-major, bit r of a column = row r from the top
+    {0x00,0x00,0x00,0x00,0x00}, {0x00,0x00,0x5F,0x00,0x00}, {0x00,0x07,0x00,0x07,0x00}, {0x14,0x7F,0x14,0x7F,0x14}, {0x24,0x2A,0x7F,0x2A,0x12},
+    {0x23,0x13,0x08,0x64,0x62}, {0x36,0x49,0x55,0x22,0x50}, {0x00,0x05,0x03,0x00,0x00}, {0x00,0x1C,0x22,0x41,0x00}, {0x00,0x41,0x22,0x1C,0x00},
+    {0x14,0x08,0x3E,0x08,0x14}, {0x08,0x08,0x3E,0x08,0x08}, {0x00,0x50,0x30,0x00,0x00}, {0x08,0x08,0x08,0x08,0x08}, {0x00,0x60,0x60,0x00,0x00},
+    {0x20,0x10,0x08,0x04,0x02}, {0x3E,0x51,0x49,0x45,0x3E}, {0x00,0x42,0x7F,0x40,0x00}, {0x42,0x61,0x51,0x49,0x46}, {0x21,0x41,0x45,0x4B,0x31},
+    {0x18,0x14,0x12,0x7F,0x10}, {0x27,0x45,0x45,0x45,0x39}, {0x3C,0x4A,0x49,0x49,0x30}, {0x01,0x71,0x09,0x05,0x03}, {0x36,0x49,0x49,0x49,0x36},
+    {0x06,0x49,0x49,0x29,0x1E}, {0x00,0x36,0x36,0x00,0x00}, {0x00,0x56,0x36,0x00,0x00}, {0x08,0x14,0x22,0x41,0x00}, {0x14,0x14,0x14,0x14,0x14},
+    {0x00,0x41,0x22,0x14,0x08}, {0x02,0x01,0x51,0x09,0x06}, {0x32,0x49,0x79,0x41,0x3E}, {0x7E,0x11,0x11,0x11,0x7E}, {0x7F,0x49,0x49,0x49,0x36},
+    {0x3E,0x41,0x41,0x41,0x22}, {0x7F,0x41,0x41,0x22,0x1C}, {0x7F,0x49,0x49,0x49,0x41}, {0x7F,0x09,0x09,0x09,0x01}, {0x3E,0x41,0x49,0x49,0x7A},
+    {0x7F,0x08,0x08,0x08,0x7F}, {0x00,0x41,0x7F,0x41,0x00}, {0x20,0x40,0x41,0x3F,0x01}, {0x7F,0x08,0x14,0x22,0x41}, {0x7F,0x40,0x40,0x40,0x40},
+    {0x7F,0x02,0x0C,0x02,0x7F}, {0x7F,0x04,0x08,0x10,0x7F}, {0x3E,0x41,0x41,0x41,0x3E}, {0x7F,0x09,0x09,0x09,0x06}, {0x3E,0x41,0x51,0x21,0x5E},
+    {0x7F,0x09,0x19,0x29,0x46}, {0x46,0x49,0x49,0x49,0x31}, {0x01,0x01,0x7F,0x01,0x01}, {0x3F,0x40,0x40,0x40,0x3F}, {0x1F,0x20,0x40,0x20,0x1F},
+    {0x3F,0x40,0x38,0x40,0x3F}, {0x63,0x14,0x08,0x14,0x63}, {0x07,0x08,0x70,0x08,0x07}, {0x61,0x51,0x49,0x45,0x43}, {0x00,0x7F,0x41,0x41,0x00},
+    {0x02,0x04,0x08,0x10,0x20}, {0x00,0x41,0x41,0x7F,0x00}, {0x04,0x02,0x01,0x02,0x04}, {0x40,0x40,0x40,0x40,0x40}, {0x00,0x01,0x02,0x04,0x00},
+    {0x20,0x54,0x54,0x54,0x78}, {0x7F,0x48,0x44,0x44,0x38}, {0x38,0x44,0x44,0x44,0x20}, {0x38,0x44,0x44,0x48,0x7F}, {0x38,0x54,0x54,0x54,0x18},
+    {0x08,0x7E,0x09,0x01,0x02}, {0x0C,0x52,0x52,0x52,0x3E}, {0x7F,0x08,0x04,0x04,0x78}, {0x00,0x44,0x7D,0x40,0x00}, {0x20,0x40,0x44,0x3D,0x00},
+    {0x7F,0x10,0x28,0x44,0x00}, {0x00,0x41,0x7F,0x40,0x00}, {0x7C,0x04,0x18,0x04,0x78}, {0x7C,0x08,0x04,0x04,0x78}, {0x38,0x44,0x44,0x44,0x38},
+    {0x7C,0x14,0x14,0x14,0x08}, {0x08,0x14,0x14,0x18,0x7C}, {0x7C,0x08,0x04,0x04,0x08}, {0x48,0x54,0x54,0x54,0x20}, {0x04,0x3F,0x44,0x40,0x20},
+    {0x3C,0x40,0x40,0x20,0x7C}, {0x1C,0x20,0x40,0x20,0x1C}, {0x3C,0x40,0x30,0x40,0x3C}, {0x44,0x28,0x10,0x28,0x44}, {0x0C,0x50,0x50,0x50,0x3C},
+    {0x44,0x64,0x54,0x4C,0x44}, {0x00,0x08,0x36,0x41,0x00}, {0x00,0x00,0x7F,0x00,0x00}, {0x00,0x41,0x36,0x08,0x00}, {0x08,0x04,0x08,0x10,0x08},
+};
+
 struct DrawArgs {
     unsigned char *img;
     const float *boxes, *classes;
     const int *valid;
     const unsigned char *colors;
-    int B, H, W, M, C, thick;
+    const unsigned char *labels;    // [B, M, L] zero-padded, or null
+    int B, H, W, M, C, thick, L, scale;
 };
 
 __global__ void __launch_bounds__(256)
 draw_boxes_kernel(const DrawArgs a) {
     const size_t total = (size_t)a.B * a.H * a.W;
     const int lo = (a.thick - 1) / 2, hi = a.thick / 2;
+    const int cell = 6 * a.scale, th = 7 * a.scale;
+    constexpr int BLACK = -2;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int x = (int)(i % a.W);
         const size_t r = i / a.W;
@@ -138,23 +172,51 @@ draw_boxes_kernel(const DrawArgs a) {
             const int y2 = (int)(bx[2] * (float)a.H), x2 = (int)(bx[3] * (float)a.W);
             const int ya = min(y1, y2), yb = max(y1, y2), xa = min(x1, x2), xb = max(x1, x2);
             const bool in_outer = x >= xa - lo && x <= xb + hi && y >= ya - lo && y <= yb + hi;
-            if (!in_outer) continue;
-            const bool on_v = (x >= xa - lo && x <= xa + hi) || (x >= xb - lo && x <= xb + hi);
-            const bool on_h = (y >= ya - lo && y <= ya + hi) || (y >= yb - lo && y <= yb + hi);
-            if (on_v || on_h) chosen = cls;
+            if (in_outer) {
+                const bool on_v = (x >= xa - lo && x <= xa + hi) || (x >= xb - lo && x <= xb + hi);
+                const bool on_h = (y >= ya - lo && y <= ya + hi) || (y >= yb - lo && y <= yb + hi);
+                if (on_v || on_h) chosen = cls;
+            }
+            if (!a.labels) continue;
+            const int dx = x - x1, dy = y - (y1 - th - 3);      // offsets inside the label rectangle
+            if (dx < 0 || dx > cell * a.L || dy < 0 || dy > th + 3) continue;
+            const unsigned char *lab = a.labels + ((size_t)b * a.M + j) * a.L;
+            if (lab[0] == 0) continue;
+            const int k = dx / cell, cx = dx - k * cell;
+            const unsigned char ch = k < a.L ? lab[k] : (unsigned char)0;
+            if (ch == 0) {
+                // right edge of the rectangle: the column x1 + text_width itself
+                if (cx == 0 && lab[k - 1] != 0) chosen = cls;
+                continue;
+            }
+            chosen = cls;
+            const int gy = dy - 1;                              // glyph rows are dy = 1 .. th
+            if (gy >= 0 && gy < th && cx < 5 * a.scale) {
+                const int code = ch >= 32 && ch <= 126 ? ch - 32 : -1;
+                const int col = cx / a.scale, row = gy / a.scale;
+                const unsigned bits = code >= 0 ? kFont5x7[code][col]
+                                                : ((col == 0 || col == 4) ? 0x7Fu : 0x41u);
+                if ((bits >> row) & 1u) chosen = BLACK;
+            }
         }
         if (chosen >= 0) {
             unsigned char *p = a.img + i * 3;
             p[0] = a.colors[chosen * 3]; p[1] = a.colors[chosen * 3 + 1]; p[2] = a.colors[chosen * 3 + 2];
+        } else if (chosen == BLACK) {
+            unsigned char *p = a.img + i * 3;
+            p[0] = 0; p[1] = 0; p[2] = 0;
         }
     }
 }
 
 int launch_draw_boxes(unsigned char *img, int B, int H, int W, const float *boxes, const float *classes, const int *valid, int M,
-                      const unsigned char *colors, int C, int thick, hipStream_t s) {
+                      const unsigned char *colors, int C, int thick, const unsigned char *labels, int L, int scale,
+                      hipStream_t s) {
     DrawArgs a;
     a.img = img; a.boxes = boxes; a.classes = classes; a.valid = valid; a.colors = colors;
     a.B = B; a.H = H; a.W = W; a.M = M; a.C = C; a.thick = thick < 1 ? 1 : thick;
+    a.labels = (labels && L > 0) ? labels : nullptr;
+    a.L = a.labels ? L : 0; a.scale = scale < 1 ? 1 : scale;
     const size_t total = (size_t)B * H * W;
     const int grid = (int)std::min<size_t>((total + 255) / 256, 65536);
     hipLaunchKernelGGL(draw_boxes_kernel, dim3(grid), dim3(256), 0, s, a);

@@ -366,10 +366,36 @@ def class_colors(num_classes):
     return np.array([[int(r * 255), int(g * 255), int(b * 255)] for r, g, b in cols], np.uint8)
 
 
-def draw_boxes(images, boxes, classes, valid_detections, num_classes, thickness=None):
+LABEL_BYTES = 48          # characters kept per label; longer strings are cut
+
+
+def label_text(name, score):
+    """The label string of utils.py:234."""
+    return '%s: %.2f' % (name, float(score))
+
+
+def encode_labels(labels, max_boxes, label_bytes=LABEL_BYTES):
+    """labels: per image a sequence of strings (one per detection, '' or None = no label) ->
+    uint8 array [B, max_boxes, label_bytes], zero-padded, characters outside Latin-1 replaced
+    by code 127 (drawn as a hollow box)."""
+    out = np.zeros((len(labels), max_boxes, label_bytes), np.uint8)
+    for b, row in enumerate(labels):
+        if len(row) > max_boxes:
+            raise ValueError("image %d has %d labels for %d detection slots" % (b, len(row), max_boxes))
+        for j, text in enumerate(row):
+            codes = [ord(c) if 0 < ord(c) < 256 else 127 for c in (text or "")][:label_bytes]
+            out[b, j, :len(codes)] = codes
+    return out
+
+
+def draw_boxes(images, boxes, classes, valid_detections, num_classes, thickness=None, labels=None, text_scale=2):
     """Outlines detections on a batch of images in place (the cv2.rectangle calls of
     utils.py:216-231).  images [B,H,W,3] uint8 on the GPU, the other arguments as
-    bbox_nms returns them.  thickness None = int(0.6 * (H + W) / 600), at least 1."""
+    bbox_nms returns them.  thickness None = int(0.6 * (H + W) / 600), at least 1.
+    labels: None, or per image a sequence of strings (one per detection) drawn as the
+    show_label branch does (utils.py:233-240): a filled rectangle in the class colour above
+    the box corner and the text in black, in the library's 5x7 bitmap typeface with
+    text_scale image pixels per font pixel."""
     _lib.require_gpu(images, boxes, classes, valid_detections)
     if images.dim() != 4 or images.shape[-1] != 3 or images.dtype != torch.uint8 or not images.is_contiguous():
         raise ValueError("images: expected contiguous uint8 [B,H,W,3]")
@@ -382,17 +408,39 @@ def draw_boxes(images, boxes, classes, valid_detections, num_classes, thickness=
     if thickness is None:
         thickness = int(0.6 * (H + W) / 600)
     colors = torch.from_numpy(class_colors(num_classes)).to(images.device)
-    _lib.launch("ymx_draw_boxes", images, _lib.ptr(images), B, H, W, _lib.ptr(bx), _lib.ptr(cl), _lib.ptr(vd),
-                bx.shape[1], _lib.ptr(colors), int(num_classes), max(int(thickness), 1))
+    if labels is None:
+        _lib.launch("ymx_draw_boxes", images, _lib.ptr(images), B, H, W, _lib.ptr(bx), _lib.ptr(cl), _lib.ptr(vd),
+                    bx.shape[1], _lib.ptr(colors), int(num_classes), max(int(thickness), 1))
+        return images
+    if len(labels) != B:
+        raise ValueError("labels: one sequence of strings per image (%d given for %d images)" % (len(labels), B))
+    lab = torch.from_numpy(encode_labels(labels, bx.shape[1])).to(images.device)
+    _lib.launch("ymx_draw_boxes_labeled", images, _lib.ptr(images), B, H, W, _lib.ptr(bx), _lib.ptr(cl), _lib.ptr(vd),
+                bx.shape[1], _lib.ptr(colors), int(num_classes), max(int(thickness), 1), _lib.ptr(lab), lab.shape[2],
+                int(text_scale))
     return images
 
 
-def draw_bbox(images, model_output, image_size, num_classes, classes=None, show_label=True):
-    """NMS on the model output, then every detection outlined on its image (utils.py:197-242).
+def draw_bbox(images, model_output, image_size, num_classes, classes=None, show_label=True, text_scale=2):
+    """NMS on the model output, then every detection outlined on its image and, with
+    show_label, captioned '<class name>: <score with two decimals>' (utils.py:197-242).
 
     images [B,H,W,3] uint8 on the GPU (drawn on in place, as the reference draws on its
-    arrays); returns the list of the B images.  Class-name labels (``classes``,
-    ``show_label``: cv2.putText in the reference) are not rendered."""
+    arrays); returns the list of the B images.  classes: the class names (default: the
+    class indices as strings, utils.py:206-207).  The captions are formatted on the host, so
+    show_label=True reads the detections back (one synchronisation); the typeface is the
+    library's bitmap font, not OpenCV's."""
     det = bbox_nms(model_output, image_size, num_classes=num_classes)
-    draw_boxes(images, det[0], det[2], det[3], num_classes)
+    labels = None
+    if show_label:
+        names = list(classes) if classes else [str(i) for i in range(num_classes)]
+        scores, cls, valid = det[1].float().cpu().numpy(), det[2].float().cpu().numpy(), det[3].cpu().numpy()
+        labels = []
+        for b in range(images.shape[0]):
+            row = []
+            for j in range(min(int(valid[b]), cls.shape[1])):
+                c = int(cls[b, j])
+                row.append(label_text(names[c], scores[b, j]) if 0 <= c < min(num_classes, len(names)) else "")
+            labels.append(row)
+    draw_boxes(images, det[0], det[2], det[3], num_classes, labels=labels, text_scale=text_scale)
     return [images[i] for i in range(images.shape[0])]
