@@ -60,6 +60,7 @@ const char *ymx_last_error(void);
  * channels; 1: without it) or on the register-staged kernel (0).  "halo_pixels": pixels per
  * tile of the resident-slab 3x3 kernel (0, the default: 192 where that shortens the launch,
  * else 256; 192 or 256 force one; rows longer than 59 pixels always take 192).
+ * "dma4_pixels": the same choice for the phase-staggered kernel (0, the default: per layer).
  * "wgrad_variant": 0 (the default) lets ymx_conv_wgrad choose: the all-taps LDS-DMA kernel for
  * 3x3 stride 1 on rows up to 459 pixels, the all-taps planar-staged kernel for 3x3 stride 2
  * with up to 32 input channels, else the per-tap LDS-DMA kernel, both for x and dz

@@ -250,11 +250,18 @@ def test_conv_dma_kernel_forced(case):
             assert torch.equal(layer(xin, residual=rin), y_small), pixels
             y32 = layer(xin, residual=rin, out_dtype=torch.float32)
             assert rel_err(y32.cpu().numpy(), want.numpy()) < 1e-3, pixels
+        _lib.check(L.ymx_set_option(b"dma_variant", 4))
+        for pixels in (192, 256):     # both tile sizes of the phase-staggered kernel
+            _lib.check(L.ymx_set_option(b"dma4_pixels", pixels))
+            assert torch.equal(layer(xin, residual=rin), y_small), pixels
+            y32 = layer(xin, residual=rin, out_dtype=torch.float32)
+            assert rel_err(y32.cpu().numpy(), want.numpy()) < 1e-3, pixels
     finally:
         _lib.check(L.ymx_set_option(b"dma_min_tiles", 160))
         _lib.check(L.ymx_set_option(b"dma_variant", 5))
         _lib.check(L.ymx_set_option(b"dma_narrow", 2))
         _lib.check(L.ymx_set_option(b"halo_pixels", 0))
+        _lib.check(L.ymx_set_option(b"dma4_pixels", 0))
 
 
 RACE_SHAPES = [   # B, H, W, Cin, Cout, k, stride: every LDS-DMA kernel family at benchmark-sized layers

@@ -309,8 +309,10 @@ def test_kernel_selection_labels():
     assert _label(_conv_op(64, 26, 26, 256, 512, 3)) == "halo192"     # 338 tiles: two rounds either way, shorter ones
     assert _label(_conv_op(64, 26, 26, 512, 1024, 3)) == "halo192"    # 3 rounds against 4 shorter ones: 72 K tiles make a 192-pixel round 0.72 of a 256-pixel one
     assert _label(_conv_op(48, 26, 26, 512, 1024, 3)) == "halo"       # 2 rounds against 3
-    assert _label(_conv_op(64, 52, 52, 1024, 512, 1)) == "dma4"
-    assert _label(_conv_op(64, 26, 26, 512, 1024, 3, stride=2)) == "dma4"
+    assert _label(_conv_op(64, 52, 52, 1024, 512, 1)) == "dma4"       # 1 352 tiles: 6 rounds against 8
+    assert _label(_conv_op(64, 26, 26, 512, 1024, 3, stride=2)) == "dma4_192"   # 172 tiles of 256 pixels: a third of the CUs idle
+    assert _label(_conv_op(64, 26, 26, 512, 256, 1)) == "dma4_192"    # 169 tiles against 226 shorter ones
+    assert _label(_conv_op(64, 104, 104, 128, 256, 3, stride=2)) == "dma4"       # 3 rounds against 4
     assert _label(_conv_op(1, 13, 13, 512, 1024, 3)) == "igemm"       # too few tiles for the large-tile kernels
     assert _label(_conv_op(1, 13, 13, 512, 1024, 3, min_tiles=1)) == "halo192"
     assert _label(_conv_op(64, 208, 208, 32, 64, 3)) == "slab2"

@@ -177,7 +177,11 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
                 int which = (int)t_opt.variant;
                 if (which == 5) which = conv_halo_eligible(a) ? 5 : 4;
                 static const char *const names[6] = {"", "dma", "dma2", "", "dma4", "halo"};
-                if (label) { *label = (which == 5 && conv_halo_tile_pixels(a) == 192) ? "halo192" : names[which]; return YMX_OK; }
+                if (label) {
+                    *label = (which == 5 && conv_halo_tile_pixels(a) == 192) ? "halo192" :
+                             (which == 4 && conv_dma4_tile_pixels(a) == 192) ? "dma4_192" : names[which];
+                    return YMX_OK;
+                }
                 int (*const fn)(const ConvArgs &, hipStream_t) = which == 1 ? launch_conv_igemm_dma : which == 2 ? launch_conv_igemm_dma2 :
                                                                   which == 4 ? launch_conv_igemm_dma4 : launch_conv_igemm_halo;
                 if (z && !(z_fused && (!residual || a.res_bytes))) return two_pass(fn);
@@ -238,6 +242,11 @@ int ymx_set_option(const char *name, long long value) {
     if (!strcmp(name, "halo_pixels")) {
         if (value != 0 && value != 192 && value != 256) return fail(YMX_EARG, "set_option: halo_pixels must be 0, 192 or 256");
         g_halo_pixels = (int)value;
+        return YMX_OK;
+    }
+    if (!strcmp(name, "dma4_pixels")) {
+        if (value != 0 && value != 192 && value != 256) return fail(YMX_EARG, "set_option: dma4_pixels must be 0, 192 or 256");
+        g_dma4_pixels = (int)value;
         return YMX_OK;
     }
     if (!strcmp(name, "wgrad_variant")) {

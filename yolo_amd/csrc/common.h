@@ -228,6 +228,8 @@ int launch_conv_igemm_halo(const ConvArgs &a, hipStream_t s);
 bool conv_halo_eligible(const ConvArgs &a);
 int conv_halo_tile_pixels(const ConvArgs &a);
 extern thread_local int g_halo_pixels;
+int conv_dma4_tile_pixels(const ConvArgs &a);
+extern thread_local int g_dma4_pixels;
 extern thread_local int g_wgrad_variant;
 int launch_conv_igemm_slab2(const ConvArgs &a, hipStream_t s);
 bool conv_slab2_eligible(const ConvArgs &a);

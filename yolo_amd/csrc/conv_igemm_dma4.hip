@@ -14,19 +14,24 @@
 //   pieces    a K tile is staged as four 16 KB pieces W(m0) X(n0) X(n1) W(m1) -- the rows of
 //             all waves' first/second channel halves and pixel halves.  Eight slots (two K
 //             tiles) of LDS; counted vmcnt waits, see the loop
+//   tiles     256 pixels (NJ = 4 blocks of 16 per wave) or 192 (NJ = 3) for layers whose
+//             256-pixel tiles fill the last round of CUs badly: the second pixel half of a wave
+//             is then one block, X(n1) carries 64 real rows (its other DMA instructions fetch
+//             nothing and keep the counted waits exact) and the intervals hold 16 / 8 / 8 / 16
+//             MFMAs -- the form conv_igemm_halo.hip has
 #include "conv_epilogue.h"
 
 namespace ymx {
 
-template <typename OT>
+template <typename OT, int NJ>
 __global__ void __launch_bounds__(512, 2)
 conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
-    constexpr int TP = 256, TQ = 256;
-    constexpr int WQ = 128, WP = 64;
-    constexpr int NI = WQ / 16, NJ = WP / 16;
+    constexpr int WQ = 128, WP = 16 * NJ;
+    constexpr int TP = 4 * WP, TQ = 256;
+    constexpr int NI = WQ / 16;
     constexpr int PIECE = 128 * 128;                        // 128 rows x 64 bf16
     constexpr unsigned OOB = 0x80000000u;
-    typedef EpiGeom<NI> Epi;
+    typedef EpiGeom<NI, 64, WP> Epi;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -45,7 +50,7 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     // ---- DMA geometry ------------------------------------------------------------------
     // A piece is 16 instructions of 8 rows x 128 B; this wave issues instructions 2*wave and
     // 2*wave+1, i.e. piece rows 16*wave + 8*i + srow.  Row r of an X piece is pixel
-    // (r>>5)*64 + half*32 + (r&31) of the tile, row r of a W piece is channel
+    // (r>>5)*WP + half*32 + (r&31) of the tile (rows past the wave's WP pixels stay empty), row r of a W piece is channel
     // (r>>6)*128 + half*64 + (r&63).  The lane that fills 16-byte slot s of a row fetches
     // K-chunk s ^ (row & 7) (the swizzle the fragment reads undo).
     const int srow = lane >> 3;
@@ -57,7 +62,8 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = 16 * wave + 8 * i + srow;
-            pixel_geometry(a, p0 + (r >> 5) * 64 + h * 32 + (r & 31), xoff[h][i], xmask[h][i]);
+            pixel_geometry(a, p0 + (r >> 5) * WP + h * 32 + (r & 31), xoff[h][i], xmask[h][i]);
+            if (h * 32 + (r & 31) >= WP) xmask[h][i] = 0u;     // no such pixel in a 48-pixel wave tile
         }
     unsigned woff[2];       // byte offset of this lane's chunk in K tile 0: [instruction], channel half 0
 #pragma unroll
@@ -147,6 +153,7 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
         const char *base = smem + ((kt & 1) * 4 + 1 + nh) * PIECE + b_row;
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
+            if (nh * 2 + jb >= NJ) continue;
             bfr[nh][jb][0] = *(const uint4 *)(base + jb * 2048 + swz0);
             bfr[nh][jb][1] = *(const uint4 *)(base + jb * 2048 + swz1);
         }
@@ -160,9 +167,16 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
             for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
-                    acc[MH * 4 + ib][NHALF * 2 + jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8_t, af[ib][kk]), __builtin_bit_cast(bf16x8_t, bfr[NHALF][jb][kk]),
-                        acc[MH * 4 + ib][NHALF * 2 + jb], 0, 0, 0);
+                    if constexpr (NHALF * 2 + 1 < NJ) {
+                        acc[MH * 4 + ib][NHALF * 2 + jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, af[ib][kk]), __builtin_bit_cast(bf16x8_t, bfr[NHALF][jb][kk]),
+                            acc[MH * 4 + ib][NHALF * 2 + jb], 0, 0, 0);
+                    } else {
+                        if (jb == 0)
+                            acc[MH * 4 + ib][NHALF * 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8_t, af[ib][kk]), __builtin_bit_cast(bf16x8_t, bfr[NHALF][0][kk]),
+                                acc[MH * 4 + ib][NHALF * 2], 0, 0, 0);
+                    }
         __builtin_amdgcn_s_setprio(0);
     };
     typedef std::integral_constant<int, 0> I0;
@@ -259,7 +273,7 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     const int cbase = q0 + wq * WQ, pbase = p0 + wp * WP;
     epi_u32x4_t rpre[Epi::NH][Epi::NPASS];
     if (epi_res_pre(a)) {
-        epi_load_res<NI>(a, 0, cbase, pbase, lane, rpre[0]);
+        epi_load_res<NI, 64, WP>(a, 0, cbase, pbase, lane, rpre[0]);
     } else {
 #pragma unroll
         for (int n = 0; n < Epi::NPASS; ++n) rpre[0][n] = epi_u32x4_t{0u, 0u, 0u, 0u};
@@ -274,13 +288,29 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     YMX_STAMP_END(5);
 }
 
-template <typename OT>
+thread_local int g_dma4_pixels = 0;      // 0: pick the tile per layer; 256 / 192: force it (tuning option "dma4_pixels")
+
+// Pixels per tile for a layer, by the rule of conv_halo_tile_pixels: a launch takes as many rounds
+// as its tiles need on the chip's 256 CUs (one workgroup per CU), and a round of 192-pixel tiles
+// costs about 0.9 of a round of 256-pixel tiles (measured 0.87-0.97 on the detector's 1x1 and
+// stride-2 layers, whose 8-36 K tiles leave the fixed costs of a tile more weight than the 3x3
+// layers of the resident-slab kernel do): 192 wins where it does not add a round.
+int conv_dma4_tile_pixels(const ConvArgs &a) {
+    if (g_dma4_pixels == 256 || g_dma4_pixels == 192) return g_dma4_pixels;
+    const long long ntq = (a.Cout + 255) / 256;
+    const long long r256 = (((long long)a.P + 255) / 256 * ntq + 255) / 256;
+    const long long r192 = (((long long)a.P + 191) / 192 * ntq + 255) / 256;
+    return (double)r192 * 0.9 < (double)r256 * 0.97 ? 192 : 256;
+}
+
+template <typename OT, int NJ>
 static int launch_dma4_cfg(const ConvArgs &a, hipStream_t s) {
     constexpr int LDS = 8 * 128 * 128;
-    auto kern = conv_igemm_dma4_kernel<OT>;
+    constexpr int TP = 64 * NJ;
+    auto kern = conv_igemm_dma4_kernel<OT, NJ>;
     static LdsReserve reserved;        // one per kernel instantiation; remembers the devices already set up
     if (const int rc = reserve_lds(reserved, (const void *)kern, LDS, "conv_igemm_dma4")) return rc;
-    const int ntile_p = (a.P + 255) / 256;
+    const int ntile_p = (a.P + TP - 1) / TP;
     const int ntile_q = (a.Cout + 255) / 256;
     const int nk = (a.K + 63) / 64;
     const long long grid = (long long)ntile_p * ntile_q;
@@ -292,10 +322,16 @@ static int launch_dma4_cfg(const ConvArgs &a, hipStream_t s) {
 // bf16 operands only; out_dtype bf16 or f32.
 int launch_conv_igemm_dma4(const ConvArgs &a, hipStream_t s) {
     if (a.dtype != YMX_BF16) return fail(YMX_EUNSUPPORTED, "conv_igemm_dma4: bf16 operands only");
-    if (a.z) return launch_dma4_cfg<bf16_zout_t>(a, s);
-    if (a.d2s_c) return launch_dma4_cfg<bf16_d2s_t>(a, s);
-    if (a.out_dtype == YMX_BF16) return launch_dma4_cfg<bf16_t>(a, s);
-    return launch_dma4_cfg<float>(a, s);
+    if (conv_dma4_tile_pixels(a) == 192) {
+        if (a.z) return launch_dma4_cfg<bf16_zout_t, 3>(a, s);
+        if (a.d2s_c) return launch_dma4_cfg<bf16_d2s_t, 3>(a, s);
+        if (a.out_dtype == YMX_BF16) return launch_dma4_cfg<bf16_t, 3>(a, s);
+        return launch_dma4_cfg<float, 3>(a, s);
+    }
+    if (a.z) return launch_dma4_cfg<bf16_zout_t, 4>(a, s);
+    if (a.d2s_c) return launch_dma4_cfg<bf16_d2s_t, 4>(a, s);
+    if (a.out_dtype == YMX_BF16) return launch_dma4_cfg<bf16_t, 4>(a, s);
+    return launch_dma4_cfg<float, 4>(a, s);
 }
 
 }  // namespace ymx
