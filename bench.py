@@ -58,6 +58,8 @@ def conv_kernel_name(op):
         return "conv_igemm_%s_bf16_256x256" % fam
     if fam == "halo192":
         return "conv_igemm_halo_bf16_256x192"
+    if fam == "dma4_192":
+        return "conv_igemm_dma4_bf16_256x192"
     if fam == "slab2":
         return "conv_igemm_slab2_bf16_cin%d" % op.Cin
     if fam == "dma2":
@@ -74,7 +76,9 @@ PMC_KERNEL = {
     "conv_igemm_halo_bf16_256x256": "conv_igemm_halo_kernel<bf16, 4>",
     "conv_igemm_halo_bf16_256x192": "conv_igemm_halo_kernel<bf16, 3>",
     "conv_igemm_dma_bf16_256x256": "conv_igemm_dma_kernel<bf16, 256>",
-    "conv_igemm_dma4_bf16_256x256": "conv_igemm_dma4_kernel<bf16>",
+    "conv_igemm_dma4_bf16_256x256": "conv_igemm_dma4_kernel<bf16, 4>",
+    "conv_igemm_dma4_bf16_256x192": "conv_igemm_dma4_kernel<bf16, 3>",
+    "conv_stem_fused": "conv_stem_kernel<2>",
 }
 
 
@@ -259,28 +263,34 @@ def profile_ops(plan, x, steps):
     plan = plan.parts[0]
     plan.ops[0].x = x.data_ptr()
     L = _lib.lib()
-    n = plan.n_ops
+    # launch units: one op each, except the first two layers where the program marks them as a pair
+    # that ymx_run_program runs as one fused launch (ymx_op.C1 on a convolution op)
+    fused = plan.n_ops > 1 and plan.ops[0].kind == 1 and plan.ops[0].C1 != 0
+    units = ([(0, 2)] if fused else []) + [(i, 1) for i in range(2 if fused else 0, plan.n_ops)]
+    n = len(units)
     acc = [0.0] * n
-    elems = [plan.ops[i] for i in range(n)]                      # views into the program array
-    op_ptr = [_lib.ctypes.byref(e) for e in elems]
+    elems = [plan.ops[i] for i in range(plan.n_ops)]             # views into the program array
+    op_ptr = [_lib.ctypes.byref(elems[i]) for i, _ in units]
     for _ in range(steps):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
-        for i in range(n):
-            ev[i].record()
-            _lib.check(L.ymx_run_program(op_ptr[i], 1, _lib.stream()))
+        for u, (i, cnt) in enumerate(units):
+            ev[u].record()
+            _lib.check(L.ymx_run_program(op_ptr[u], cnt, _lib.stream()))
         ev[n].record()
         torch.cuda.synchronize()
-        for i in range(n):
-            acc[i] += ev[i].elapsed_time(ev[i + 1])
+        for u in range(n):
+            acc[u] += ev[u].elapsed_time(ev[u + 1])
     groups = {}
-    for i in range(n):
-        name = conv_kernel_name(plan.ops[i])
+    per_op = []
+    for u, (i, cnt) in enumerate(units):
+        name = "conv_stem_fused" if cnt == 2 else conv_kernel_name(plan.ops[i])
+        flops = sum(conv_flops(plan.ops[j]) for j in range(i, i + cnt))
         g = groups.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
         g["launches"] += 1
-        g["ms"] += acc[i] / steps
-        g["flops"] += conv_flops(plan.ops[i])
-    per_op = [(conv_kernel_name(plan.ops[i]), acc[i] / steps, conv_flops(plan.ops[i]),
-               (plan.ops[i].H, plan.ops[i].Cin, plan.ops[i].Cout, plan.ops[i].k, plan.ops[i].stride)) for i in range(n)]
+        g["ms"] += acc[u] / steps
+        g["flops"] += flops
+        o = plan.ops[i + cnt - 1]
+        per_op.append((name, acc[u] / steps, flops, (o.H, o.Cin, o.Cout, o.k, o.stride)))
     return groups, per_op
 
 

@@ -121,6 +121,20 @@ int ymx_conv2d_fused_ex(const void *x, const void *w, const void *scale, const v
 int ymx_upsample2x_concat(const void *skip, const void *x, void *y, int B, int H, int W,
                           int C1, int C2, int dtype, void *stream);
 
+/* ---- the backbone's first two layers in one launch ---------------------------
+ * Replaces the pair YOLOConv((3,3,32)), YOLOConv((3,3,64), downsample=True) that opens
+ * Darknet53 and CSPDarknet53 (backbones.py:11-12, 64-66; YOLOConv.call layers.py:77-90)
+ * when nothing else reads the 32-channel map: it is kept in LDS tile by tile instead of being
+ * written to memory and read back.  Results are bit-identical to two ymx_conv2d_fused_ex calls.
+ *   x [B,H,W,3] fp32 (dense);  w0: the first layer's weights as ymx_pack_weights gives them for
+ *   Cin = 3 (HWIO fp32);  w1: the second layer's bf16 packed weights (k = 3, Cin = 32, Cout = 64);
+ *   scale*, shift*: per layer as in ymx_conv2d_fused (NULL = 1 / 0);  act: both layers' activation,
+ *   YMX_ACT_MISH or YMX_ACT_LEAKY;  y [B, OH, OW, 64] bf16 with OH = (H - 2) / 2 + 1 (padding
+ *   top/left as for every stride-2 layer), pixel stride y_ld elements (0 = 64). */
+int ymx_conv_stem_fused(const void *x, const void *w0, const void *scale0, const void *shift0,
+                        const void *w1, const void *scale1, const void *shift1, void *y,
+                        int B, int H, int W, int act, int y_ld, void *stream);
+
 /* ---- whole-network executor -------------------------------------------------
  * Replaces the Python layer loops Darknet53.call (backbones.py:44-60) and
  * YoloV3.call (detectors.py:46-77): a pre-planned list of the two ops above,
@@ -130,7 +144,10 @@ typedef struct ymx_op {
     int32_t B, H, W, Cin, Cout, k, stride, act;
     int32_t dtype, x_dtype, out_dtype;
     int32_t x_ld, res_ld, y_ld;
-    int32_t C1, C2;               /* upsample2x_concat only */
+    int32_t C1, C2;               /* upsample2x_concat: channels of skip and x.  conv: C1 != 0 says that
+                                     the output is read by the next op alone; ymx_run_program then
+                                     runs the pair as ymx_conv_stem_fused when it has that shape and
+                                     does not write this op's output */
     int32_t min_tiles;            /* conv only: fewest 256-wide tiles for which the large-tile LDS-DMA
                                      kernels are chosen; 0 = the library's "dma_min_tiles" option.
                                      Programs meant to share the GPU with another stream's program

@@ -264,6 +264,66 @@ def test_conv_dma_kernel_forced(case):
         _lib.check(L.ymx_set_option(b"dma4_pixels", 0))
 
 
+STEM_CASES = [   # B, H, W, activation, batch norm
+    (2, 64, 64, "mish", False), (1, 416, 416, "mish", False), (3, 50, 38, "leaky", True), (2, 33, 47, "mish", True),
+    (1, 17, 130, "leaky", False), (5, 16, 32, "mish", False), (1, 2, 2, "mish", False), (1, 19, 5, "leaky", False),
+]
+
+
+@pytest.mark.parametrize("case", range(len(STEM_CASES)))
+def test_conv_stem_fused_matches_two_launches(case):
+    """The backbone's first two layers (backbones.py:11-12) as one launch: the same bits as the
+    first-layer kernel followed by the stride-2 kernel, for image sizes on and off the 8 x 16
+    output tiles (odd sides, maps smaller than a tile), both activations, bias and folded batch
+    norm; and within the bf16 tolerance of the oracle's two layers."""
+    from yolo_amd import _lib
+    B, H, W, act, bn = STEM_CASES[case]
+    g = torch.Generator().manual_seed(900 + case)
+    x = torch.rand(B, H, W, 3, generator=g)
+    params = []
+    for cin, cout in ((3, 32), (32, 64)):
+        p = {"kernel": N.bf16_round(torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5)}
+        if bn:
+            p.update(gamma=1 + 0.2 * torch.randn(cout, generator=g), beta=0.1 * torch.randn(cout, generator=g),
+                     mean=0.1 * torch.randn(cout, generator=g), var=0.5 + torch.rand(cout, generator=g))
+        else:
+            p["bias"] = 0.1 * torch.randn(cout, generator=g)
+        params.append(p)
+    l0 = make_conv(params[0], 3, False, act, bn, torch.bfloat16)
+    l1 = make_conv(params[1], 3, True, act, bn, torch.bfloat16)
+    xin = x.to(DEV)
+    mid = l0(xin)
+    want = l1(mid)
+    w0, sc0, sh0, _ = l0.packed(torch.bfloat16)
+    w1, sc1, sh1, _ = l1.packed(torch.bfloat16)
+    y = torch.full_like(want, float("nan"))
+    _lib.launch("ymx_conv_stem_fused", xin, _lib.ptr(xin), _lib.ptr(w0), _lib.ptr(sc0), _lib.ptr(sh0), _lib.ptr(w1), _lib.ptr(sc1),
+                _lib.ptr(sh1), _lib.ptr(y), B, H, W, _lib.ACT_MISH if act == "mish" else _lib.ACT_LEAKY, 0)
+    assert torch.equal(y, want), float((y.float() - want.float()).abs().max())
+    # through the program executor: op 0 marked as read by op 1 alone
+    ops = (_lib.ymx_op * 2)()
+    y2 = torch.full_like(want, float("nan"))
+    mid2 = torch.full_like(mid, float("nan"))
+    for o, (layer, src, dst, cin, cout, stride, w, sc, sh) in zip(ops, ((l0, xin, mid2, 3, 32, 1, w0, sc0, sh0),
+                                                                          (l1, mid2, y2, 32, 64, 2, w1, sc1, sh1))):
+        o.kind, o.B, o.H, o.W, o.Cin, o.Cout, o.k, o.stride, o.act = 1, B, H, W, cin, cout, 3, stride, layer.act_code
+        o.dtype = o.out_dtype = _lib.BF16
+        o.x_dtype = _lib.F32 if cin == 3 else _lib.BF16
+        o.x, o.w, o.y = src.data_ptr(), w.data_ptr(), dst.data_ptr()
+        o.scale = None if sc is None else sc.data_ptr()
+        o.shift = None if sh is None else sh.data_ptr()
+    ops[0].C1 = 1
+    _lib.check(_lib.lib().ymx_run_program(ops, 2, _lib.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(y2, want) and bool(torch.isnan(mid2.float()).all())      # fused: the 32-channel map was never written
+    ops[0].C1 = 0
+    _lib.check(_lib.lib().ymx_run_program(ops, 2, _lib.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(mid2, mid) and torch.equal(y2, want)
+    ref = N.yolo_conv(N.bf16_round(N.yolo_conv(x, params[0], False, act)), params[1], True, act)
+    assert rel_err(y.float().cpu().numpy(), ref.numpy()) < 2e-2
+
+
 RACE_SHAPES = [   # B, H, W, Cin, Cout, k, stride: every LDS-DMA kernel family at benchmark-sized layers
     (64, 26, 26, 256, 512, 3, 1), (48, 13, 13, 512, 1024, 3, 1), (64, 52, 52, 1024, 512, 1, 1),
     (64, 26, 26, 512, 1024, 3, 2), (64, 208, 208, 32, 64, 3, 1), (48, 104, 104, 64, 128, 3, 1),

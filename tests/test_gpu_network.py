@@ -455,6 +455,35 @@ def test_concurrent_sub_batches_equal_whole_batch():
             assert torch.equal(u[:2], v)
 
 
+def test_fused_stem_equals_two_launches_in_the_detector():
+    """The planned path runs the backbone's first two layers as one launch (Detector(fuse_stem=True),
+    the default): same heads and detections, bit for bit, as with the two separate launches, whole
+    batch and concurrent sub-batches, and the 32-channel map between them is never written."""
+    from yolo_amd import Detector
+    C = 80
+    for side, batch, cut in ((160, 3, "off"), (224, 5, (3, 2))):
+        x = _image(batch, side).to(DEV)
+        outs = []
+        for fuse in (False, True):
+            det = Detector(num_classes=C, dtype=torch.bfloat16, seed=5, split=cut, fuse_stem=fuse).to(DEV)
+            det.calibrate_(x[:2].contiguous())
+            plan = det._plan(batch, side, x.dtype, x.device)
+            assert all(int(part.ops[0].C1) == int(fuse) for part in plan.parts)
+            mids = [part.keep[0] for part in plan.parts]        # the first layer's output buffers
+            for m in mids:
+                assert tuple(m.shape[1:]) == (side, side, 32)
+                m.fill_(float("nan"))
+            got = det(x)
+            heads = det.forward_heads(x)
+            torch.cuda.synchronize()
+            for m in mids:
+                assert bool(torch.isnan(m.float()).all()) == fuse
+            outs.append([t.clone() for t in got] + [got.keep_idx.clone()] + [h.clone() for h in heads])
+        assert int(outs[0][3].min()) > 0
+        for u, v in zip(*outs):
+            assert torch.equal(u, v)
+
+
 def test_decode_beside_matrix_kernels_screen():
     """Bounded screen for results that depend on what else runs on the GPU.  The decode+filter
     launch is repeated on one stream while a second stream keeps the matrix pipes busy (a

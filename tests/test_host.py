@@ -102,6 +102,21 @@ def test_label_encoding_and_labeled_draw_validation():
     assert L.ymx_draw_boxes_labeled(one, 0, 8, 8, one, one, one, 4, one, 3, 1, one, 16, 2, None) == -1
 
 
+def test_fused_stem_entry_point_validates_without_gpu():
+    from yolo_amd import _lib
+    L = _lib.lib()
+    one = ctypes.c_void_p(256)
+    args = lambda **kw: [kw.get("x", one), one, None, one, kw.get("w1", one), None, one, kw.get("y", one),
+                         kw.get("B", 2), kw.get("H", 64), kw.get("W", 64), kw.get("act", 2), kw.get("y_ld", 0), None]
+    assert L.ymx_conv_stem_fused(*args(x=None)) == -1 and b"null" in L.ymx_last_error()
+    assert L.ymx_conv_stem_fused(*args(H=1)) == -1
+    assert L.ymx_conv_stem_fused(*args(y_ld=60)) == -1 and b"y_ld" in L.ymx_last_error()
+    assert L.ymx_conv_stem_fused(*args(y_ld=66)) == -1
+    assert L.ymx_conv_stem_fused(*args(w1=ctypes.c_void_p(264))) == -1 and b"aligned" in L.ymx_last_error()
+    assert L.ymx_conv_stem_fused(*args(act=0)) == -2 and b"activation" in L.ymx_last_error()
+    assert L.ymx_conv_stem_fused(*args(B=64, H=2048, W=2048)) == -2          # the image batch must stay under 2 GB
+
+
 def test_module_interface_matches_reference():
     import yolo_amd
     from yolo_amd import layers, backbones, detectors

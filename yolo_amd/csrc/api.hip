@@ -344,12 +344,41 @@ int ymx_upsample2x_concat(const void *skip, const void *x, void *y, int B, int H
     return launch_upsample2x_concat(skip, x, y, B, H, W, C1, C2, dtype, (hipStream_t)stream);
 }
 
+int ymx_conv_stem_fused(const void *x, const void *w0, const void *scale0, const void *shift0, const void *w1,
+                        const void *scale1, const void *shift1, void *y, int B, int H, int W, int act, int y_ld, void *stream) {
+    if (!x || !w0 || !w1 || !y) return fail(YMX_EARG, "conv_stem_fused: null pointer");
+    if (B <= 0 || H < 2 || W < 2) return fail(YMX_EARG, "conv_stem_fused: B=%d H=%d W=%d", B, H, W);
+    if (y_ld != 0 && (y_ld < 64 || (y_ld & 3))) return fail(YMX_EARG, "conv_stem_fused: y_ld=%d (0, or a multiple of 4 not below 64)", y_ld);
+    if (!aligned16(w1) || !aligned16(y) || (((uintptr_t)x | (uintptr_t)w0) & 3))
+        return fail(YMX_EARG, "conv_stem_fused: w1 and y must be 16-byte aligned, x and w0 4-byte aligned");
+    return launch_conv_stem((const float *)x, (const float *)w0, (const float *)scale0, (const float *)shift0, w1,
+                            (const float *)scale1, (const float *)shift1, y, B, H, W, act, y_ld, (hipStream_t)stream);
+}
+
+// Op i is the network's first layer on an fp32 image, marked as read by op i + 1 alone, and op
+// i + 1 is the 3x3 stride-2 layer to 64 channels that reads it: the pair the fused kernel takes.
+static bool stem_pair(const ymx_op &o, const ymx_op &n) {
+    return o.kind == 1 && n.kind == 1 && o.C1 != 0 &&
+           o.Cin == 3 && o.Cout == 32 && o.k == 3 && o.stride == 1 && o.dtype == YMX_BF16 && o.x_dtype == YMX_F32 &&
+           o.out_dtype == YMX_BF16 && !o.residual && (o.x_ld == 0 || o.x_ld == 3) && (o.y_ld == 0 || o.y_ld == 32) &&
+           n.Cin == 32 && n.Cout == 64 && n.k == 3 && n.stride == 2 && n.dtype == YMX_BF16 && n.x_dtype == YMX_BF16 &&
+           n.out_dtype == YMX_BF16 && !n.residual && n.x == o.y && n.B == o.B && n.H == o.H && n.W == o.W &&
+           (n.x_ld == 0 || n.x_ld == 32) && o.act == n.act && conv_stem_supported(o.act) && o.H >= 2 && o.W >= 2;
+}
+
 int ymx_run_program(const ymx_op *ops, int n_ops, void *stream) {
     if (!ops || n_ops < 0) return fail(YMX_EARG, "run_program: bad program");
     for (int i = 0; i < n_ops; ++i) {
         const ymx_op &o = ops[i];
-        int rc;
-        if (o.kind == 1)
+        int rc = YMX_EUNSUPPORTED;
+        if (i + 1 < n_ops && stem_pair(o, ops[i + 1])) {
+            const ymx_op &n = ops[i + 1];
+            rc = ymx_conv_stem_fused(o.x, o.w, o.scale, o.shift, n.w, n.scale, n.shift, n.y, o.B, o.H, o.W, o.act, n.y_ld, stream);
+            if (rc == YMX_OK) { ++i; continue; }
+        }
+        if (rc != YMX_EUNSUPPORTED) {
+            // the fused launch failed for a reason the two separate launches would share
+        } else if (o.kind == 1)
             rc = conv_impl(o.x, o.w, o.scale, o.shift, o.residual, o.y, o.B, o.H, o.W, o.Cin, o.Cout, o.k, o.stride,
                            o.act, o.dtype, o.x_dtype, o.out_dtype, o.x_ld, o.res_ld, o.y_ld, (hipStream_t)stream, o.min_tiles);
         else if (o.kind == 2)

@@ -35,16 +35,20 @@ _SHARED_MIN_TILES = 80
 
 class Detector(nn.Module):
     def __init__(self, num_classes=80, dtype=torch.bfloat16, seed=0, max_outputs_per_class=32, max_outputs=32,
-                 iou_threshold=0.45, score_threshold=0.25, split="auto"):
+                 iou_threshold=0.45, score_threshold=0.25, split="auto", fuse_stem=True):
         """``split``: how a batch is cut into sub-batches that run concurrently on separate
         HIP streams (the tail of one sub-batch's launch overlaps the other's work):
         "auto" = time a few cuts once per input shape and keep the fastest, "off" = never,
-        or a tuple of sub-batch sizes used for batches of exactly their sum."""
+        or a tuple of sub-batch sizes used for batches of exactly their sum.
+        fuse_stem: the backbone's first two layers (backbones.py:11-12) run as one launch that
+        keeps the 32-channel full-resolution map in LDS (same bits as the two launches; the map
+        is then never written, so per-layer hooks on the planned path need fuse_stem=False)."""
         super().__init__()
         if not (split in ("auto", "off") or (isinstance(split, (tuple, list)) and split and
                                             all(isinstance(n, int) and n > 0 for n in split))):
             raise ValueError("split must be 'auto', 'off' or a tuple of positive sub-batch sizes")
         self.split = split
+        self.fuse_stem = bool(fuse_stem)
         self._side_streams = {}             # device -> streams of the sub-batches after the first
         self.num_classes = num_classes
         self.dtype = dtype
@@ -211,6 +215,10 @@ class Detector(nn.Module):
         s, _, _ = run_stack(list(hd.sbbox_layer_stack)[:-1], s, h1, w1)
         s, _, _ = conv(hd.sbbox_layer_stack[-1], s, h1, w1, out_dtype=hd.out_dtype, head=0)
 
+        if self.fuse_stem and len(ops) > 1 and ops[1].x == ops[0].y:
+            # the first layer's output is read by the second layer alone: ymx_run_program may run
+            # the pair as one launch (it checks the shapes itself)
+            ops[0].C1 = 1
         part = _Plan()
         part.B, part.start = n, start
         part.ops = (_lib.ymx_op * len(ops))(*ops)
