@@ -274,6 +274,13 @@ for step in range(2):
         for a, g_ in zip(ref, gs):
             a.add_(g_ / WORLD)
     ok = ok and all(torch.allclose(a, b, rtol=1e-5, atol=1e-6) for a, b in zip(got, ref))
+# rehearse=True: the collectives are issued in a group of one rank too
+rp = torch.nn.Parameter(torch.zeros(10))
+rb = D.GradientBuckets([rp], hooks=False, rehearse=True)
+rb.begin(); rp.grad.add_(2.0); rb.reduce()
+ok = ok and len(rb._handles) == 1
+rb.wait()
+ok = ok and torch.allclose(rp.grad, torch.full_like(rp, 2.0))
 dist.barrier(); dist.destroy_process_group()
 sys.exit(0 if ok else 3)
 """

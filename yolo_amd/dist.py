@@ -113,8 +113,10 @@ class GradientBuckets(object):
 
     ALIGN = 64                                  # elements: 256 bytes of fp32
 
-    def __init__(self, params, bucket_bytes=64 << 20, group=None, hooks=True):
+    def __init__(self, params, bucket_bytes=64 << 20, group=None, hooks=True, rehearse=False):
         self.group = group
+        self.rehearse = bool(rehearse)          # issue the collectives in a group of one rank too (each is then an identity):
+                                                # runs the transport's code path on a single GPU
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []                       # flat tensors
         self.members = []                       # per bucket: its parameters
@@ -149,7 +151,8 @@ class GradientBuckets(object):
         self.begin(zero=False)
 
     def _active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return dist.is_available() and dist.is_initialized() and \
+            (dist.get_world_size(self.group) > 1 or self.rehearse)
 
     def begin(self, zero=True):
         """Start of a step: gradients zeroed (autograd adds into them), nothing ready."""
