@@ -58,6 +58,10 @@ def conv_kernel_name(op):
         return "conv_igemm_%s_bf16_256x256" % fam
     if fam == "halo192":
         return "conv_igemm_halo_bf16_256x192"
+    if fam == "halo_mixed":
+        return "conv_igemm_halo_bf16_256x256+192"
+    if fam == "dma4_mixed":
+        return "conv_igemm_dma4_bf16_256x256+192"
     if fam == "dma4_192":
         return "conv_igemm_dma4_bf16_256x192"
     if fam == "slab2":
@@ -75,6 +79,8 @@ def conv_kernel_name(op):
 PMC_KERNEL = {
     "conv_igemm_halo_bf16_256x256": "conv_igemm_halo_kernel<bf16, 4>",
     "conv_igemm_halo_bf16_256x192": "conv_igemm_halo_kernel<bf16, 3>",
+    "conv_igemm_halo_bf16_256x256+192": "conv_igemm_halo_mixed_kernel<bf16>",
+    "conv_igemm_dma4_bf16_256x256+192": "conv_igemm_dma4_mixed_kernel<bf16>",
     "conv_igemm_dma_bf16_256x256": "conv_igemm_dma_kernel<bf16, 256>",
     "conv_igemm_dma4_bf16_256x256": "conv_igemm_dma4_kernel<bf16, 4>",
     "conv_igemm_dma4_bf16_256x192": "conv_igemm_dma4_kernel<bf16, 3>",

@@ -264,6 +264,53 @@ def test_conv_dma_kernel_forced(case):
         _lib.check(L.ymx_set_option(b"dma4_pixels", 0))
 
 
+MIXED_SHAPES = [   # B, H, W, Cin, Cout, activation, shortcut: launches of two to four rounds of 256-pixel tiles
+    (64, 52, 52, 128, 256, "mish", True),        # 676 tiles: 512 of 256 pixels + 219 of 192
+    (61, 26, 26, 128, 1000, "leaky", False),     # partial last pixel tile of the 192-pixel part, partial channel tile
+    (33, 40, 40, 64, 512, "mish", True),         # 207 pixel tiles x 2: one whole round of 256-pixel tiles, ragged rest
+]
+
+
+@pytest.mark.parametrize("case", range(len(MIXED_SHAPES)))
+def test_conv_halo_mixed_tiles(case):
+    """The resident-slab kernel with both tile forms in one launch (whole rounds of 256-pixel tiles,
+    the remaining pixels as 192-pixel tiles): the same bits as either pure form, bf16 and fp32
+    outputs, and the layer's own choice among the three is one of them."""
+    from yolo_amd import _lib
+    B, H, W, cin, cout, act, use_res = MIXED_SHAPES[case]
+    g = torch.Generator().manual_seed(700 + case)
+    xin = torch.randn(B, H, W, cin, generator=g).to(DEV).bfloat16()
+    p = {"kernel": N.bf16_round(torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5),
+         "bias": 0.1 * torch.randn(cout, generator=g)}
+    rin = torch.randn(B, H, W, cout, generator=g).to(DEV).bfloat16() if use_res else None
+    layer = make_conv(p, 3, False, act, False, torch.bfloat16)
+    L = _lib.lib()
+    op = _lib.ymx_op()
+    op.kind, op.B, op.H, op.W, op.Cin, op.Cout, op.k, op.stride = 1, B, H, W, cin, cout, 3, 1
+    op.dtype = op.x_dtype = op.out_dtype = _lib.BF16
+    op.x = op.w = op.y = 256
+    import ctypes
+    try:
+        outs = {}
+        for pixels in (256, 192, 448):
+            _lib.check(L.ymx_set_option(b"halo_pixels", pixels))
+            assert L.ymx_conv_kernel_label(ctypes.byref(op)).decode() == {256: "halo", 192: "halo192", 448: "halo_mixed"}[pixels]
+            outs[pixels] = (layer(xin, residual=rin).clone(), layer(xin, residual=rin, out_dtype=torch.float32).clone())
+        for pixels in (192, 448):
+            assert torch.equal(outs[pixels][0], outs[256][0]), pixels
+            assert torch.equal(outs[pixels][1], outs[256][1]), pixels
+        _lib.check(L.ymx_set_option(b"halo_pixels", 0))
+        assert torch.equal(layer(xin, residual=rin), outs[256][0])
+        # against the oracle on a slice of the batch (first and last image)
+        for b in (0, B - 1):
+            want = N.yolo_conv(xin[b:b + 1].float().cpu(), p, False, act)
+            if use_res:
+                want = want + rin[b:b + 1].float().cpu()
+            assert rel_err(outs[448][1][b:b + 1].cpu().numpy(), want.numpy()) < 1e-3
+    finally:
+        _lib.check(L.ymx_set_option(b"halo_pixels", 0))
+
+
 STEM_CASES = [   # B, H, W, activation, batch norm
     (2, 64, 64, "mish", False), (1, 416, 416, "mish", False), (3, 50, 38, "leaky", True), (2, 33, 47, "mish", True),
     (1, 17, 130, "leaky", False), (5, 16, 32, "mish", False), (1, 2, 2, "mish", False), (1, 19, 5, "leaky", False),

@@ -323,18 +323,21 @@ def _label(op):
 
 def test_kernel_selection_labels():
     """Which kernel family a layer is routed to, asked of the library (no GPU needed)."""
-    assert _label(_conv_op(64, 52, 52, 512, 1024, 3)) == "halo"
+    assert _label(_conv_op(64, 52, 52, 512, 1024, 3)) == "halo_mixed"   # 2 704 tiles = 10.56 rounds: 2 560 tiles of 256 pixels + 192 short ones
+    assert _label(_conv_op(48, 52, 52, 128, 256, 3)) == "halo"          # 507 tiles: two rounds either way
     assert _label(_conv_op(64, 76, 76, 512, 1024, 3)) == "halo192"    # rows too long for two slabs of 256-pixel tiles
     assert _label(_conv_op(32, 91, 91, 512, 1024, 3)) == "halo192"
-    assert _label(_conv_op(32, 92, 92, 512, 1024, 3)) == "dma4"       # rows too long for two resident slabs of any tile
+    assert _label(_conv_op(32, 92, 92, 512, 1024, 3)).startswith("dma4")   # rows too long for two resident slabs of any tile
     assert _label(_conv_op(64, 13, 13, 512, 1024, 3)) == "halo192"    # 172 tiles of 256 pixels would idle a third of the CUs
     assert _label(_conv_op(64, 26, 26, 256, 512, 3)) == "halo192"     # 338 tiles: two rounds either way, shorter ones
-    assert _label(_conv_op(64, 26, 26, 512, 1024, 3)) == "halo192"    # 3 rounds against 4 shorter ones: 72 K tiles make a 192-pixel round 0.72 of a 256-pixel one
+    assert _label(_conv_op(64, 26, 26, 512, 1024, 3)) == "halo_mixed"  # 676 tiles: two rounds of 256-pixel tiles and one of 220 192-pixel tiles (2.72 against 3 or 4 x 0.72)
+    assert _label(_conv_op(64, 52, 52, 128, 256, 3)) == "halo_mixed"   # 676 tiles again (one channel tile): 512 + 219 short ones
     assert _label(_conv_op(48, 26, 26, 512, 1024, 3)) == "halo"       # 2 rounds against 3
-    assert _label(_conv_op(64, 52, 52, 1024, 512, 1)) == "dma4"       # 1 352 tiles: 6 rounds against 8
+    assert _label(_conv_op(64, 52, 52, 1024, 512, 1)) == "dma4_mixed" # 1 352 tiles = 5.28 rounds: 5 rounds of 256-pixel tiles + 96 short ones
+    assert _label(_conv_op(48, 52, 52, 1024, 512, 1)) == "dma4"       # 1 014 tiles: 4 rounds
     assert _label(_conv_op(64, 26, 26, 512, 1024, 3, stride=2)) == "dma4_192"   # 172 tiles of 256 pixels: a third of the CUs idle
     assert _label(_conv_op(64, 26, 26, 512, 256, 1)) == "dma4_192"    # 169 tiles against 226 shorter ones
-    assert _label(_conv_op(64, 104, 104, 128, 256, 3, stride=2)) == "dma4"       # 3 rounds against 4
+    assert _label(_conv_op(64, 104, 104, 128, 256, 3, stride=2)) == "dma4_mixed"  # 676 tiles: 512 + 219 short ones
     assert _label(_conv_op(1, 13, 13, 512, 1024, 3)) == "igemm"       # too few tiles for the large-tile kernels
     assert _label(_conv_op(1, 13, 13, 512, 1024, 3, min_tiles=1)) == "halo192"
     assert _label(_conv_op(64, 208, 208, 32, 64, 3)) == "slab2"
@@ -362,7 +365,7 @@ def test_options_are_per_thread():
     from yolo_amd import _lib
     L = _lib.lib()
     op_args = (64, 52, 52, 512, 1024, 3)
-    want = {1: "dma", 4: "dma4", 5: "halo"}
+    want = {1: "dma", 4: "dma4_mixed", 5: "halo_mixed"}
     errors = []
     start = threading.Barrier(3)
 
@@ -385,18 +388,18 @@ def test_options_are_per_thread():
         t.join()
     assert not errors, errors[:3]
     # this thread never set anything: defaults, whatever the workers did
-    assert _label(_conv_op(*op_args)) == "halo"
+    assert _label(_conv_op(*op_args)) == "halo_mixed"
     seen = []
     t = threading.Thread(target=lambda: seen.append(_label(_conv_op(*op_args))))
     t.start(); t.join()
-    assert seen == ["halo"]
+    assert seen == ["halo_mixed"]
     # min_tiles too: a thread that disables the large-tile kernels does not affect this one
     def disable():
         _lib.check(L.ymx_set_option(b"dma_min_tiles", 1 << 40))
         seen.append(_label(_conv_op(*op_args)))
     t = threading.Thread(target=disable)
     t.start(); t.join()
-    assert seen[-1] == "igemm" and _label(_conv_op(*op_args)) == "halo"
+    assert seen[-1] == "igemm" and _label(_conv_op(*op_args)) == "halo_mixed"
 
 
 # ---- TFRecord shards (dataset.py:56-126) ------------------------------------------------------------

@@ -1,4 +1,4 @@
-"""256- against 192-pixel tiles of the resident-slab kernel on the detector's wide 3x3 layers, at the
+"""256- against 192-pixel tiles (and both forms in one launch) of the resident-slab kernel on the detector's wide 3x3 layers, at the
 batch sizes the engine runs (whole batch and the two concurrent sub-batches), with the choice the
 library's cost model makes (tuning aid).    python tools/halo_tile_sweep.py"""
 import ctypes
@@ -45,9 +45,10 @@ def main():
             _lib.check(L.ymx_set_option(b"halo_pixels", 0))
             label = L.ymx_conv_kernel_label(ctypes.byref(op)).decode()
             res = {}
-            for px in (256, 192):
+            for px in (256, 192, 448):               # 448 = both forms in one launch
                 _lib.check(L.ymx_set_option(b"halo_pixels", px))
-                if not L.ymx_conv_kernel_label(ctypes.byref(op)).decode().startswith("halo"):
+                got = L.ymx_conv_kernel_label(ctypes.byref(op)).decode()
+                if not got.startswith("halo") or (px == 448 and got != "halo_mixed"):
                     continue
                 res[px] = time_layer(layer, x)
             _lib.check(L.ymx_set_option(b"halo_pixels", 0))
@@ -55,7 +56,7 @@ def main():
             best = min(res, key=res.get) if res else None
             print("B%-3d %2dx%-2d %4d->%-4d  model: %-8s  " % (B, hw, hw, cin, cout, label) +
                   "  ".join("%d: %.4f ms %5.0f TF" % (px, ms, flops / ms / 1e9) for px, ms in res.items()) +
-                  ("   best %s%s" % (best, "" if (label == "halo192") == (best == 192) else "   <-- model differs") if res else ""), flush=True)
+                  ("   best %s%s" % (best, "" if {"halo": 256, "halo192": 192, "halo_mixed": 448}.get(label) == best else "   <-- model differs") if res else ""), flush=True)
 
 
 if __name__ == "__main__":

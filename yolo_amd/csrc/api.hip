@@ -179,7 +179,9 @@ static int conv_impl(const void *x, const void *w, const void *scale, const void
                 static const char *const names[6] = {"", "dma", "dma2", "", "dma4", "halo"};
                 if (label) {
                     *label = (which == 5 && conv_halo_tile_pixels(a) == 192) ? "halo192" :
-                             (which == 4 && conv_dma4_tile_pixels(a) == 192) ? "dma4_192" : names[which];
+                             (which == 5 && conv_halo_tile_pixels(a) == 448) ? "halo_mixed" :
+                             (which == 4 && conv_dma4_tile_pixels(a) == 192) ? "dma4_192" :
+                             (which == 4 && conv_dma4_tile_pixels(a) == 448) ? "dma4_mixed" : names[which];
                     return YMX_OK;
                 }
                 int (*const fn)(const ConvArgs &, hipStream_t) = which == 1 ? launch_conv_igemm_dma : which == 2 ? launch_conv_igemm_dma2 :
@@ -240,12 +242,24 @@ int ymx_set_option(const char *name, long long value) {
         return YMX_OK;
     }
     if (!strcmp(name, "halo_pixels")) {
-        if (value != 0 && value != 192 && value != 256) return fail(YMX_EARG, "set_option: halo_pixels must be 0, 192 or 256");
+        if (value != 0 && value != 192 && value != 256 && value != 448)
+            return fail(YMX_EARG, "set_option: halo_pixels must be 0, 192, 256 or 448 (both forms in one launch)");
         g_halo_pixels = (int)value;
         return YMX_OK;
     }
+    if (!strcmp(name, "tile_mix")) {
+        if (value != 0 && value != 1) return fail(YMX_EARG, "set_option: tile_mix must be 0 or 1");
+        g_tile_mix = (int)value;
+        return YMX_OK;
+    }
+    if (!strcmp(name, "halo_big_rounds")) {
+        if (value < 0 || value > 1000000) return fail(YMX_EARG, "set_option: halo_big_rounds must be 0 (all but the last round) or a positive count");
+        g_halo_big_rounds = (int)value;
+        return YMX_OK;
+    }
     if (!strcmp(name, "dma4_pixels")) {
-        if (value != 0 && value != 192 && value != 256) return fail(YMX_EARG, "set_option: dma4_pixels must be 0, 192 or 256");
+        if (value != 0 && value != 192 && value != 256 && value != 448)
+            return fail(YMX_EARG, "set_option: dma4_pixels must be 0, 192, 256 or 448 (both forms in one launch)");
         g_dma4_pixels = (int)value;
         return YMX_OK;
     }

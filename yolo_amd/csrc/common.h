@@ -226,8 +226,12 @@ int launch_conv_igemm_dma2(const ConvArgs &a, hipStream_t s);
 int launch_conv_igemm_dma4(const ConvArgs &a, hipStream_t s);
 int launch_conv_igemm_halo(const ConvArgs &a, hipStream_t s);
 bool conv_halo_eligible(const ConvArgs &a);
-int conv_halo_tile_pixels(const ConvArgs &a);
-extern thread_local int g_halo_pixels;
+int conv_halo_tile_pixels(const ConvArgs &a);         // 256, 192, or 448 = both forms in one launch
+struct TilePlan { int pixels, big_tiles, big_pixels; };   // mixed form (448): the first big_tiles workgroups cover big_pixels pixels with 256-pixel tiles
+TilePlan plan_wide_tiles(long long P, long long ntq, double f192, int forced_pixels, int forced_rounds);
+TilePlan conv_halo_plan(const ConvArgs &a);
+TilePlan conv_dma4_plan(const ConvArgs &a);
+extern thread_local int g_halo_pixels, g_halo_big_rounds, g_tile_mix;
 int conv_dma4_tile_pixels(const ConvArgs &a);
 extern thread_local int g_dma4_pixels;
 extern thread_local int g_wgrad_variant;

@@ -23,11 +23,10 @@
 
 namespace ymx {
 
+// One output tile: 64 * NJ pixels from p0, 256 channels from q0.
 template <typename OT, int NJ>
-__global__ void __launch_bounds__(512, 2)
-conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
+__device__ __forceinline__ void dma4_tile(const ConvArgs &a, const int p0, const int q0, const int nk) {
     constexpr int WQ = 128, WP = 16 * NJ;
-    constexpr int TP = 4 * WP, TQ = 256;
     constexpr int NI = WQ / 16;
     constexpr int PIECE = 128 * 128;                        // 128 rows x 64 bf16
     constexpr unsigned OOB = 0x80000000u;
@@ -40,9 +39,6 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wq = wave & 1, wp = wave >> 1;                // wave tile position (as in the other kernels)
     const int group = wave >> 2;
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
-    const int tq = id % ntile_q, tp = id / ntile_q;
-    const int p0 = tp * TP, q0 = tq * TQ;
     const i32x4_t xrsrc = make_rsrc(a.x, a.x_bytes);
     const i32x4_t wrsrc = make_rsrc(a.w, a.w_bytes);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
@@ -288,6 +284,28 @@ conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
     YMX_STAMP_END(5);
 }
 
+template <typename OT, int NJ>
+__global__ void __launch_bounds__(512, 2)
+conv_igemm_dma4_kernel(const ConvArgs a, const int ntile_q, const int nk) {
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    dma4_tile<OT, NJ>(a, (id / ntile_q) * (64 * NJ), (id % ntile_q) * 256, nk);
+}
+
+// Both tile forms in one launch (see conv_igemm_halo_mixed_kernel): the first `nbig` workgroups take
+// 256-pixel tiles over the pixels below `pbig`, the rest 192-pixel tiles from there on.
+template <typename OT>
+__global__ void __launch_bounds__(512, 2)
+conv_igemm_dma4_mixed_kernel(const ConvArgs a, const int ntile_q, const int nk, const int nbig, const int pbig) {
+    const int b = blockIdx.x;
+    if (b < nbig) {
+        const int id = xcd_remap(b, nbig);
+        dma4_tile<OT, 4>(a, (id / ntile_q) * 256, (id % ntile_q) * 256, nk);
+    } else {
+        const int id = xcd_remap(b - nbig, (int)gridDim.x - nbig);
+        dma4_tile<OT, 3>(a, pbig + (id / ntile_q) * 192, (id % ntile_q) * 256, nk);
+    }
+}
+
 thread_local int g_dma4_pixels = 0;      // 0: pick the tile per layer; 256 / 192: force it (tuning option "dma4_pixels")
 
 // Pixels per tile for a layer, by the rule of conv_halo_tile_pixels: a launch takes as many rounds
@@ -295,13 +313,10 @@ thread_local int g_dma4_pixels = 0;      // 0: pick the tile per layer; 256 / 19
 // costs about 0.9 of a round of 256-pixel tiles (measured 0.87-0.97 on the detector's 1x1 and
 // stride-2 layers, whose 8-36 K tiles leave the fixed costs of a tile more weight than the 3x3
 // layers of the resident-slab kernel do): 192 wins where it does not add a round.
-int conv_dma4_tile_pixels(const ConvArgs &a) {
-    if (g_dma4_pixels == 256 || g_dma4_pixels == 192) return g_dma4_pixels;
-    const long long ntq = (a.Cout + 255) / 256;
-    const long long r256 = (((long long)a.P + 255) / 256 * ntq + 255) / 256;
-    const long long r192 = (((long long)a.P + 191) / 192 * ntq + 255) / 256;
-    return (double)r192 * 0.9 < (double)r256 * 0.97 ? 192 : 256;
+TilePlan conv_dma4_plan(const ConvArgs &a) {
+    return plan_wide_tiles(a.P, (a.Cout + 255) / 256, 0.9, g_dma4_pixels, g_halo_big_rounds);
 }
+int conv_dma4_tile_pixels(const ConvArgs &a) { return conv_dma4_plan(a).pixels; }
 
 template <typename OT, int NJ>
 static int launch_dma4_cfg(const ConvArgs &a, hipStream_t s) {
@@ -319,10 +334,33 @@ static int launch_dma4_cfg(const ConvArgs &a, hipStream_t s) {
     return check_launch("conv_igemm_dma4");
 }
 
+template <typename OT>
+static int launch_dma4_mixed(const ConvArgs &a, const TilePlan &pl, hipStream_t s) {
+    constexpr int LDS = 8 * 128 * 128;
+    auto kern = conv_igemm_dma4_mixed_kernel<OT>;
+    static LdsReserve reserved;
+    if (const int rc = reserve_lds(reserved, (const void *)kern, LDS, "conv_igemm_dma4 (mixed)")) return rc;
+    const int ntile_q = (a.Cout + 255) / 256;
+    const long long rest = (long long)a.P - pl.big_pixels;
+    if (pl.big_tiles <= 0 || (pl.big_tiles & 7) || rest <= 0 || (long long)pl.big_tiles * 256 != (long long)pl.big_pixels * ntile_q)
+        return fail(YMX_EARG, "conv_igemm_dma4: inconsistent mixed tiling");
+    const long long grid = pl.big_tiles + (rest + 191) / 192 * ntile_q;
+    if (grid > 0x7fffffffLL) return fail(YMX_EUNSUPPORTED, "conv_igemm_dma4: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, a, ntile_q, (a.K + 63) / 64, pl.big_tiles, pl.big_pixels);
+    return check_launch("conv_igemm_dma4 (mixed)");
+}
+
 // bf16 operands only; out_dtype bf16 or f32.
 int launch_conv_igemm_dma4(const ConvArgs &a, hipStream_t s) {
     if (a.dtype != YMX_BF16) return fail(YMX_EUNSUPPORTED, "conv_igemm_dma4: bf16 operands only");
-    if (conv_dma4_tile_pixels(a) == 192) {
+    const TilePlan pl = conv_dma4_plan(a);
+    if (pl.pixels == 448) {
+        if (a.z) return launch_dma4_mixed<bf16_zout_t>(a, pl, s);
+        if (a.d2s_c) return launch_dma4_mixed<bf16_d2s_t>(a, pl, s);
+        if (a.out_dtype == YMX_BF16) return launch_dma4_mixed<bf16_t>(a, pl, s);
+        return launch_dma4_mixed<float>(a, pl, s);
+    }
+    if (pl.pixels == 192) {
         if (a.z) return launch_dma4_cfg<bf16_zout_t, 3>(a, s);
         if (a.d2s_c) return launch_dma4_cfg<bf16_d2s_t, 3>(a, s);
         if (a.out_dtype == YMX_BF16) return launch_dma4_cfg<bf16_t, 3>(a, s);

@@ -42,11 +42,10 @@ namespace ymx {
 // 256-pixel tiles fill the last round of CUs badly).  With three blocks the second pixel half
 // of a wave is one block, so the phases carry 16, 8, 8 and 16 MFMAs; loads, waits and barriers
 // are the same in both forms.
+// One output tile: TP = 64 * NJ pixels from p0, 256 channels from q0.
 template <typename OT, int NJ>
-__global__ void __launch_bounds__(512, 2)
-conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const int npieces) {
+__device__ __forceinline__ void halo_tile(const ConvArgs &a, const int p0, const int q0, const int ncb, const int npieces) {
     constexpr int WQ = 128, WP = 16 * NJ;
-    constexpr int TP = 4 * WP, TQ = 256;
     constexpr int NI = WQ / 16;
     constexpr int WPIECE = 128 * 128;                       // 128 channel rows x 64 bf16
     constexpr unsigned OOB = 0x80000000u;
@@ -59,9 +58,6 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wq = wave & 1, wp = wave >> 1;                // wave tile position (as in the other kernels)
     const int group = wave >> 2;
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
-    const int tq = id % ntile_q, tp = id / ntile_q;
-    const int p0 = tp * TP, q0 = tq * TQ;
     const int nk = ncb * 9;
     const i32x4_t xrsrc = make_rsrc(a.x, a.x_bytes);
     const i32x4_t wrsrc = make_rsrc(a.w, a.w_bytes);
@@ -323,30 +319,109 @@ conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const
     YMX_STAMP_END(5);
 }
 
+template <typename OT, int NJ>
+__global__ void __launch_bounds__(512, 2)
+conv_igemm_halo_kernel(const ConvArgs a, const int ntile_q, const int ncb, const int npieces) {
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tq = id % ntile_q, tp = id / ntile_q;
+    halo_tile<OT, NJ>(a, tp * (64 * NJ), tq * 256, ncb, npieces);
+}
+
+// Both tile forms in one launch: the first `nbig` workgroups (a whole number of rounds of the
+// chip) take 256-pixel tiles over the pixels below `pbig`, the rest 192-pixel tiles over the
+// pixels from there on.  A launch of 2.6 rounds of 256-pixel tiles then costs two such rounds
+// and a shorter one instead of three (workgroups are dispatched in id order, so the short tiles
+// run last).  Each segment keeps the XCD-contiguous tile order of its own (nbig is a multiple of 8).
+template <typename OT>
+__global__ void __launch_bounds__(512, 2)
+conv_igemm_halo_mixed_kernel(const ConvArgs a, const int ntile_q, const int ncb, const int npieces4, const int npieces3,
+                             const int nbig, const int pbig) {
+    const int b = blockIdx.x;
+    if (b < nbig) {
+        const int id = xcd_remap(b, nbig);
+        halo_tile<OT, 4>(a, (id / ntile_q) * 256, (id % ntile_q) * 256, ncb, npieces4);
+    } else {
+        const int id = xcd_remap(b - nbig, (int)gridDim.x - nbig);
+        halo_tile<OT, 3>(a, pbig + (id / ntile_q) * 192, (id % ntile_q) * 256, ncb, npieces3);
+    }
+}
+
 // The shapes this kernel takes: 3x3, stride 1, whole 64-channel blocks, rows short enough
 // for two slabs to fit in LDS.
 bool conv_halo_eligible(const ConvArgs &a) {
     return a.dtype == YMX_BF16 && a.k == 3 && a.stride == 1 && a.Cin % 64 == 0 && a.W <= 91;
 }
 
-thread_local int g_halo_pixels = 0;      // 0: pick the tile per layer; 256 / 192: force it (tuning option "halo_pixels")
+thread_local int g_tile_mix = 1;         // 0: the layer's own choice is between the two pure forms only (tuning option "tile_mix")
+thread_local int g_halo_big_rounds = 0;  // mixed form: whole rounds of 256-pixel tiles (0: all but the last; tuning option "halo_big_rounds")
+thread_local int g_halo_pixels = 0;      // 0: pick the tile form per layer; 256 / 192: force it; 448: force the mixed form where one exists (tuning option "halo_pixels")
 
-// Pixels per tile for a layer: 192 when that shortens the launch.  A launch takes as many
-// rounds as its tiles need on the chip's 256 CUs (one workgroup per CU), and a round of
-// 192-pixel tiles takes about 0.82 of a round of 256-pixel tiles (three quarters of the MFMAs
-// behind the same barriers).  Layers with few tiles gain: 172 tiles of 256 pixels leave a
-// third of the CUs idle for a whole round where 228 tiles of 192 fill the chip for a shorter one.
-int conv_halo_tile_pixels(const ConvArgs &a) {
-    if (a.W > 59) return 192;                  // two slabs of a 256-pixel tile would not fit in LDS
-    if (g_halo_pixels == 256 || g_halo_pixels == 192) return g_halo_pixels;
+// How a wide layer's launch is tiled (this kernel and conv_igemm_dma4.hip).  A launch takes as many
+// rounds as its tiles need on the chip's 256 CUs (one workgroup per CU), and a round of 192-pixel
+// tiles takes `f192` of a round of 256-pixel tiles (three quarters of the MFMAs behind the same
+// barriers and fixed costs).  Layers with few tiles gain from the short form: 172 tiles of 256
+// pixels leave a third of the CUs idle for a whole round where 228 tiles of 192 fill the chip for
+// a shorter one.  The mixed form runs whole rounds of 256-pixel tiles and the remaining pixels as
+// 192-pixel tiles: 676 tiles of 256 pixels are three rounds, 512 of them plus 219 short ones two
+// rounds and a short one; 2 704 tiles (10.56 rounds) run as 2 560 + 192 short ones.  The few
+// candidates nearest the end of the launch are priced (more short rounds can beat fewer: 5.28
+// rounds measure faster as 4 + 2 short ones than as 5 + a sparse short one).  Measured gains of
+// the mixed form exceed the priced ones (the short tiles at the end also run beside fewer busy
+// CUs: 512 -> 1024 @ 52 x 52, batch 64: 1.20 ms as 11 rounds, 1.09 as 10 + 1 short), so a small
+// margin suffices.
+TilePlan plan_wide_tiles(long long P, long long ntq, double f192, int forced_pixels, int forced_rounds) {
+    TilePlan pl = {192, 0, 0};
+    const long long t256 = (P + 255) / 256, t192 = (P + 191) / 192;
+    const long long r256 = (t256 * ntq + 255) / 256;
+    const long long r192 = (t192 * ntq + 255) / 256;
+    double cmix = 1e30;
+    long long big_ptiles = 0;
+    if (r256 >= 2 && ntq <= 256) {
+        const long long first = forced_rounds > 0 ? (forced_rounds < r256 ? forced_rounds : r256 - 1) : (r256 > 4 ? r256 - 4 : 1);
+        const long long last = forced_rounds > 0 ? first : r256 - 1;
+        for (long long rounds = first; rounds <= last; ++rounds) {
+            const long long bp = rounds * 256 / ntq;
+            const long long rest = P - bp * 256;
+            if (bp <= 0 || rest <= 0 || bp * ntq % 8 != 0 || bp * 256 >= 0x7fffffffLL) continue;
+            // the short tiles: whole rounds after a few rounds of big tiles; after many, the workgroups have drifted
+            // apart and a partly filled last round costs little more than its share (2 560 + 192 tiles measure as
+            // 10.0 big rounds, 512 + 219 as 2.66, 256 + 110 as 1.88)
+            const long long n3 = (rest + 191) / 192 * ntq;
+            const double whole = (double)((n3 + 255) / 256), frac = (double)n3 / 256.0;
+            const double drift = rounds >= 10 ? 1.0 : (double)rounds / 10.0;
+            const double c = (double)(bp * ntq) / 256.0 + (whole - (whole - frac) * drift) * f192;
+            if (c < cmix) { cmix = c; big_ptiles = bp; }
+        }
+    }
+    const double c256 = (double)r256, c192 = (double)r192 * f192;
+    if (forced_pixels == 256) { pl.pixels = 256; return pl; }
+    if (forced_pixels == 192) return pl;
+    if (cmix < 1e29 && (forced_pixels == 448 || (g_tile_mix && cmix < 0.985 * (c256 < c192 ? c256 : c192)))) {
+        pl.pixels = 448;
+        pl.big_tiles = (int)(big_ptiles * ntq);
+        pl.big_pixels = (int)(big_ptiles * 256);
+        return pl;
+    }
+    pl.pixels = c192 < c256 * 0.97 ? 192 : 256;
+    return pl;
+}
+
+TilePlan conv_halo_plan(const ConvArgs &a) {
+    if (a.W > 59) return TilePlan{192, 0, 0};                   // two slabs of a 256-pixel tile would not fit in LDS
     const long long ntq = (a.Cout + 255) / 256;
     const long long r256 = (((long long)a.P + 255) / 256 * ntq + 255) / 256;
-    const long long r192 = (((long long)a.P + 191) / 192 * ntq + 255) / 256;
     // (layers of 512 and more input channels, 72+ K tiles, in launches of a few rounds: the fixed costs of a
-    // tile weigh less and a 192-pixel round measures 0.70-0.73 of a 256-pixel one; with more rounds the
-    // workgroups drift apart, whole rounds stop being the unit, and 256-pixel tiles measure faster again)
+    // tile weigh less and a 192-pixel round measures 0.70-0.73 of a 256-pixel one)
     const double f192 = (a.Cin >= 512 && r256 <= 4) ? 0.72 : 0.82;
-    return (double)r192 * f192 < (double)r256 * 0.97 ? 192 : 256;
+    return plan_wide_tiles(a.P, ntq, f192, g_halo_pixels, g_halo_big_rounds);
+}
+
+int conv_halo_tile_pixels(const ConvArgs &a) { return conv_halo_plan(a).pixels; }
+
+static int halo_lds_bytes(int npieces, int nj) {
+    int lds = 2 * npieces * 1024 + 4 * 128 * 128 + 1024;
+    const int epi = nj == 4 ? 8 * EpiGeom<8, 64, 64>::LDS_BYTES : 8 * EpiGeom<8, 64, 48>::LDS_BYTES;      // the epilogue's transpose images
+    return lds < epi ? epi : lds;
 }
 
 template <typename OT, int NJ>
@@ -354,8 +429,7 @@ static int launch_halo_cfg(const ConvArgs &a, hipStream_t s) {
     constexpr int TP = 64 * NJ;
     const int npieces = (TP + 2 * a.W + 2 + 7) / 8;
     if (npieces > 47) return fail(YMX_EUNSUPPORTED, "conv_igemm_halo: rows of %d pixels do not fit", a.W);
-    int lds = 2 * npieces * 1024 + 4 * 128 * 128 + 1024;
-    if (lds < 8 * EpiGeom<8, 64, 16 * NJ>::LDS_BYTES) lds = 8 * EpiGeom<8, 64, 16 * NJ>::LDS_BYTES;      // the epilogue's transpose images
+    const int lds = halo_lds_bytes(npieces, NJ);
     auto kern = conv_igemm_halo_kernel<OT, NJ>;
     static LdsReserve reserved;        // one per kernel instantiation; remembers the devices already set up
     if (const int rc = reserve_lds(reserved, (const void *)kern, 160 * 1024, "conv_igemm_halo")) return rc;
@@ -367,9 +441,34 @@ static int launch_halo_cfg(const ConvArgs &a, hipStream_t s) {
     return check_launch("conv_igemm_halo");
 }
 
+template <typename OT>
+static int launch_halo_mixed(const ConvArgs &a, const TilePlan &pl, hipStream_t s) {
+    const int np4 = (256 + 2 * a.W + 2 + 7) / 8, np3 = (192 + 2 * a.W + 2 + 7) / 8;
+    if (np4 > 47) return fail(YMX_EUNSUPPORTED, "conv_igemm_halo: rows of %d pixels do not fit", a.W);
+    const int l4 = halo_lds_bytes(np4, 4), l3 = halo_lds_bytes(np3, 3);
+    auto kern = conv_igemm_halo_mixed_kernel<OT>;
+    static LdsReserve reserved;
+    if (const int rc = reserve_lds(reserved, (const void *)kern, 160 * 1024, "conv_igemm_halo (mixed)")) return rc;
+    const int ntile_q = (a.Cout + 255) / 256;
+    const long long rest = (long long)a.P - pl.big_pixels;
+    if (pl.big_tiles <= 0 || (pl.big_tiles & 7) || rest <= 0 || (long long)pl.big_tiles * 256 != (long long)pl.big_pixels * ntile_q)
+        return fail(YMX_EARG, "conv_igemm_halo: inconsistent mixed tiling");
+    const long long grid = pl.big_tiles + (rest + 191) / 192 * ntile_q;
+    if (grid > 0x7fffffffLL) return fail(YMX_EUNSUPPORTED, "conv_igemm_halo: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), l4 > l3 ? l4 : l3, s, a, ntile_q, a.Cin / 64, np4, np3,
+                       pl.big_tiles, pl.big_pixels);
+    return check_launch("conv_igemm_halo (mixed)");
+}
+
 int launch_conv_igemm_halo(const ConvArgs &a, hipStream_t s) {
     if (!conv_halo_eligible(a)) return fail(YMX_EUNSUPPORTED, "conv_igemm_halo: shape not supported");
-    if (conv_halo_tile_pixels(a) == 192) {
+    const TilePlan pl = conv_halo_plan(a);
+    if (pl.pixels == 448) {
+        if (a.z) return launch_halo_mixed<bf16_zout_t>(a, pl, s);
+        if (a.out_dtype == YMX_BF16) return launch_halo_mixed<bf16_t>(a, pl, s);
+        return launch_halo_mixed<float>(a, pl, s);
+    }
+    if (pl.pixels == 192) {
         if (a.z) return launch_halo_cfg<bf16_zout_t, 3>(a, s);
         if (a.out_dtype == YMX_BF16) return launch_halo_cfg<bf16_t, 3>(a, s);
         return launch_halo_cfg<float, 3>(a, s);
