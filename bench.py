@@ -85,6 +85,7 @@ PMC_KERNEL = {
     "conv_igemm_dma4_bf16_256x256": "conv_igemm_dma4_kernel<bf16, 4>",
     "conv_igemm_dma4_bf16_256x192": "conv_igemm_dma4_kernel<bf16, 3>",
     "conv_stem_fused": "conv_stem_kernel<2>",
+    "conv_resblock_fused": "conv_resblock_kernel<2>",
 }
 
 
@@ -269,10 +270,13 @@ def profile_ops(plan, x, steps):
     plan = plan.parts[0]
     plan.ops[0].x = x.data_ptr()
     L = _lib.lib()
-    # launch units: one op each, except the first two layers where the program marks them as a pair
-    # that ymx_run_program runs as one fused launch (ymx_op.C1 on a convolution op)
-    fused = plan.n_ops > 1 and plan.ops[0].kind == 1 and plan.ops[0].C1 != 0
-    units = ([(0, 2)] if fused else []) + [(i, 1) for i in range(2 if fused else 0, plan.n_ops)]
+    # launch units: one op each, except where the program marks a convolution as read by the next op alone
+    # (ymx_op.C1): ymx_run_program runs such a pair as one fused launch (the first two layers, the first ResidialBlock)
+    units, i = [], 0
+    while i < plan.n_ops:
+        cnt = 2 if (plan.ops[i].kind == 1 and plan.ops[i].C1 != 0 and i + 1 < plan.n_ops) else 1
+        units.append((i, cnt))
+        i += cnt
     n = len(units)
     acc = [0.0] * n
     elems = [plan.ops[i] for i in range(plan.n_ops)]             # views into the program array
@@ -289,7 +293,7 @@ def profile_ops(plan, x, steps):
     groups = {}
     per_op = []
     for u, (i, cnt) in enumerate(units):
-        name = "conv_stem_fused" if cnt == 2 else conv_kernel_name(plan.ops[i])
+        name = ("conv_stem_fused" if plan.ops[i].Cin == 3 else "conv_resblock_fused") if cnt == 2 else conv_kernel_name(plan.ops[i])
         flops = sum(conv_flops(plan.ops[j]) for j in range(i, i + cnt))
         g = groups.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
         g["launches"] += 1

@@ -130,10 +130,24 @@ int ymx_upsample2x_concat(const void *skip, const void *x, void *y, int B, int H
  *   Cin = 3 (HWIO fp32);  w1: the second layer's bf16 packed weights (k = 3, Cin = 32, Cout = 64);
  *   scale*, shift*: per layer as in ymx_conv2d_fused (NULL = 1 / 0);  act: both layers' activation,
  *   YMX_ACT_MISH or YMX_ACT_LEAKY;  y [B, OH, OW, 64] bf16 with OH = (H - 2) / 2 + 1 (padding
- *   top/left as for every stride-2 layer), pixel stride y_ld elements (0 = 64). */
+ *   top/left as for every stride-2 layer), pixel stride y_ld elements (0 = 64, else a multiple of 8). */
 int ymx_conv_stem_fused(const void *x, const void *w0, const void *scale0, const void *shift0,
                         const void *w1, const void *scale1, const void *shift1, void *y,
                         int B, int H, int W, int act, int y_ld, void *stream);
+
+/* ---- a narrow ResidialBlock in one launch -------------------------------------
+ * Replaces ResidialBlock(32, 64) on a 64-channel map (layers.py:92-106: x + conv3x3(conv1x1(x)),
+ * both YOLOConv with bias or folded batch norm and the same activation; the first block of
+ * Darknet53, backbones.py:13) when nothing else reads the 32-channel map: it is kept in LDS tile by
+ * tile, and x is read once for both the 1x1 convolution and the shortcut.  Results are
+ * bit-identical to the two ymx_conv2d_fused_ex calls of the block.
+ *   x [B,H,W,64] bf16, pixel stride x_ld elements (0 = 64);  w1 / w2: the bf16 packed weights of the
+ *   1x1 (Cin = 64, Cout = 32) and the 3x3 (Cin = 32, Cout = 64) convolution;  scale*, shift* per
+ *   layer as in ymx_conv2d_fused (NULL = 1 / 0);  act: YMX_ACT_MISH or YMX_ACT_LEAKY;
+ *   y [B,H,W,64] bf16, pixel stride y_ld elements (0 = 64), not x;  the strides are multiples of 8. */
+int ymx_conv_resblock_fused(const void *x, const void *w1, const void *scale1, const void *shift1,
+                            const void *w2, const void *scale2, const void *shift2, void *y,
+                            int B, int H, int W, int act, int x_ld, int y_ld, void *stream);
 
 /* ---- whole-network executor -------------------------------------------------
  * Replaces the Python layer loops Darknet53.call (backbones.py:44-60) and
@@ -146,8 +160,8 @@ typedef struct ymx_op {
     int32_t x_ld, res_ld, y_ld;
     int32_t C1, C2;               /* upsample2x_concat: channels of skip and x.  conv: C1 != 0 says that
                                      the output is read by the next op alone; ymx_run_program then
-                                     runs the pair as ymx_conv_stem_fused when it has that shape and
-                                     does not write this op's output */
+                                     runs the pair as ymx_conv_stem_fused or ymx_conv_resblock_fused
+                                     when it has that shape and does not write this op's output */
     int32_t min_tiles;            /* conv only: fewest 256-wide tiles for which the large-tile LDS-DMA
                                      kernels are chosen; 0 = the library's "dma_min_tiles" option.
                                      Programs meant to share the GPU with another stream's program

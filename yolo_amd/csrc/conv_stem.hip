@@ -270,24 +270,33 @@ conv_stem_kernel(const StemArgs a) {
         YMX_REGION_BEGIN(5);
 
         // ---- epilogue: lane = (pixel column li, channels 4g .. 4g+3 of each 16-channel block) ----
-        const int oc = cur.c0 + li;
+        // The bf16 results go through a 2 KB image private to the wave (in the tile's LDS, which every
+        // wave is done with) and leave as 16-byte stores, 64 contiguous bytes per pixel: 8-byte stores
+        // straight from the accumulator layout touch every 128-byte line of y eight times.
+        // image: pixel p = 16 j + li at p * 64, 16-byte slot s (8 channels) at (s ^ ((p >> 1) & 3)) * 16
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int orow = cur.r0 + 2 * wp + j;
-            if (orow < a.OH && oc < a.OW) {
-                bf16_t *yp = a.y + ((size_t)(cur.b * a.OH + orow) * a.OW + oc) * a.y_ld + wq * 32 + 4 * g;
+            const int p = 16 * j + li;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const f32x2_t o0 = act2<ACT>(affine2(f32x2_t{acc[i][j][0], acc[i][j][1]}, f32x2_t{sc1[i][0], sc1[i][1]},
-                                                         f32x2_t{sh1[i][0], sh1[i][1]}));
-                    const f32x2_t o1 = act2<ACT>(affine2(f32x2_t{acc[i][j][2], acc[i][j][3]}, f32x2_t{sc1[i][2], sc1[i][3]},
-                                                         f32x2_t{sh1[i][2], sh1[i][3]}));
-                    const stem_u32x2_t v = {epi_pack2(o0), epi_pack2(o1)};
-                    __builtin_nontemporal_store(v, (stem_u32x2_t *)(yp + i * 16));
-                }
+            for (int i = 0; i < 2; ++i) {
+                const f32x2_t o0 = act2<ACT>(affine2(f32x2_t{acc[i][j][0], acc[i][j][1]}, f32x2_t{sc1[i][0], sc1[i][1]},
+                                                     f32x2_t{sh1[i][0], sh1[i][1]}));
+                const f32x2_t o1 = act2<ACT>(affine2(f32x2_t{acc[i][j][2], acc[i][j][3]}, f32x2_t{sc1[i][2], sc1[i][3]},
+                                                     f32x2_t{sh1[i][2], sh1[i][3]}));
+                *(stem_u32x2_t *)(l0 + wave * 2048 + p * 64 + (((2 * i + (g >> 1)) ^ ((p >> 1) & 3)) << 4) + (g & 1) * 8) =
+                    stem_u32x2_t{epi_pack2(o0), epi_pack2(o1)};
             }
         }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int p = 16 * h + (lane >> 2), s = lane & 3;         // h = the wave's output row, lane >> 2 = column, s = 8-channel chunk
+            const int orow = cur.r0 + 2 * wp + h, oc = cur.c0 + (lane >> 2);
+            const epi_u32x4_t v = *(const epi_u32x4_t *)(l0 + wave * 2048 + p * 64 + ((s ^ ((p >> 1) & 3)) << 4));
+            if (orow < a.OH && oc < a.OW)
+                __builtin_nontemporal_store(v, (epi_u32x4_t *)(a.y + ((size_t)(cur.b * a.OH + orow) * a.OW + oc) * a.y_ld + wq * 32 + s * 8));
+        }
         YMX_REGION_END(5);
+        __syncthreads();                                       // the images are read: the next phase A may overwrite the tile
         cur = nxt;
     }
     YMX_REGION_STORE(wave, lane);
