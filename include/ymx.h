@@ -136,18 +136,19 @@ int ymx_conv_stem_fused(const void *x, const void *w0, const void *scale0, const
                         int B, int H, int W, int act, int y_ld, void *stream);
 
 /* ---- a narrow ResidialBlock in one launch -------------------------------------
- * Replaces ResidialBlock(32, 64) on a 64-channel map (layers.py:92-106: x + conv3x3(conv1x1(x)),
- * both YOLOConv with bias or folded batch norm and the same activation; the first block of
- * Darknet53, backbones.py:13) when nothing else reads the 32-channel map: it is kept in LDS tile by
- * tile, and x is read once for both the 1x1 convolution and the shortcut.  Results are
- * bit-identical to the two ymx_conv2d_fused_ex calls of the block.
- *   x [B,H,W,64] bf16, pixel stride x_ld elements (0 = 64);  w1 / w2: the bf16 packed weights of the
- *   1x1 (Cin = 64, Cout = 32) and the 3x3 (Cin = 32, Cout = 64) convolution;  scale*, shift* per
+ * Replaces ResidialBlock(C/2, C) on a C-channel map, C = 64 or 128 (layers.py:92-106:
+ * x + conv3x3(conv1x1(x)), both YOLOConv with bias or folded batch norm and the same activation;
+ * the first three blocks of Darknet53, backbones.py:13-16) when nothing else reads the
+ * C/2-channel map: it is kept in LDS tile by tile, and x is read once for both the 1x1
+ * convolution and the shortcut.  Results are bit-identical to the two ymx_conv2d_fused_ex calls
+ * of the block.
+ *   x [B,H,W,C] bf16, pixel stride x_ld elements (0 = C);  w1 / w2: the bf16 packed weights of the
+ *   1x1 (Cin = C, Cout = C/2) and the 3x3 (Cin = C/2, Cout = C) convolution;  scale*, shift* per
  *   layer as in ymx_conv2d_fused (NULL = 1 / 0);  act: YMX_ACT_MISH or YMX_ACT_LEAKY;
- *   y [B,H,W,64] bf16, pixel stride y_ld elements (0 = 64), not x;  the strides are multiples of 8. */
+ *   y [B,H,W,C] bf16, pixel stride y_ld elements (0 = C), not x;  the strides are multiples of 8. */
 int ymx_conv_resblock_fused(const void *x, const void *w1, const void *scale1, const void *shift1,
                             const void *w2, const void *scale2, const void *shift2, void *y,
-                            int B, int H, int W, int act, int x_ld, int y_ld, void *stream);
+                            int B, int H, int W, int C, int act, int x_ld, int y_ld, void *stream);
 
 /* ---- whole-network executor -------------------------------------------------
  * Replaces the Python layer loops Darknet53.call (backbones.py:44-60) and

@@ -756,26 +756,30 @@ def test_bbox_iou_giou():
         np.testing.assert_allclose(got, ref(a, b), rtol=1e-5, atol=1e-6)
 
 
-RESBLOCK_CASES = [   # B, H, W, activation, batch norm
-    (2, 64, 64, "mish", False), (1, 208, 208, "mish", False), (3, 50, 38, "leaky", True), (2, 33, 47, "mish", True),
-    (1, 17, 130, "leaky", False), (5, 8, 16, "mish", False), (1, 1, 1, "mish", False), (1, 19, 5, "leaky", False),
-    (2, 9, 17, "mish", False), (1, 7, 15, "mish", True),
+RESBLOCK_CASES = [   # B, H, W, activation, batch norm, channels
+    (2, 64, 64, "mish", False, 64), (1, 208, 208, "mish", False, 64), (3, 50, 38, "leaky", True, 64), (2, 33, 47, "mish", True, 64),
+    (1, 17, 130, "leaky", False, 64), (5, 8, 16, "mish", False, 64), (1, 1, 1, "mish", False, 64), (1, 19, 5, "leaky", False, 64),
+    (2, 9, 17, "mish", False, 64), (1, 7, 15, "mish", True, 64),
+    (2, 64, 64, "mish", False, 128), (1, 104, 104, "mish", False, 128), (3, 50, 38, "leaky", True, 128), (2, 33, 47, "mish", True, 128),
+    (1, 17, 130, "leaky", False, 128), (5, 8, 16, "mish", False, 128), (1, 1, 1, "mish", False, 128), (1, 19, 5, "leaky", False, 128),
+    (2, 9, 17, "mish", False, 128), (300, 8, 16, "mish", True, 128),
 ]
 
 
 @pytest.mark.parametrize("case", range(len(RESBLOCK_CASES)))
 def test_conv_resblock_fused_matches_two_launches(case):
-    """ResidialBlock(32, 64) on a 64-channel map (backbones.py:13) as one launch: the same bits as the
+    """ResidialBlock(32, 64) on a 64-channel map and ResidialBlock(64, 128) on a 128-channel map
+    (backbones.py:13-16) as one launch: the same bits as the
     1x1 kernel followed by the 3x3 kernel with the shortcut, for map sizes on and off the 8 x 16
     output tiles (odd sides, maps smaller than a tile, one pixel past a tile), both activations,
     bias and folded batch norm; through the C entry point and through the program executor (the
     32-channel map is then never written); and within the bf16 tolerance of the oracle's block."""
     from yolo_amd import _lib
-    B, H, W, act, bn = RESBLOCK_CASES[case]
+    B, H, W, act, bn, C = RESBLOCK_CASES[case]
     g = torch.Generator().manual_seed(950 + case)
-    x = N.bf16_round(torch.randn(B, H, W, 64, generator=g))
+    x = N.bf16_round(torch.randn(B, H, W, C, generator=g))
     params = []
-    for k, cin, cout in ((1, 64, 32), (3, 32, 64)):
+    for k, cin, cout in ((1, C, C // 2), (3, C // 2, C)):
         p = {"kernel": N.bf16_round(torch.randn(k, k, cin, cout, generator=g) * (2.0 / (k * k * cin)) ** 0.5)}
         if bn:
             p.update(gamma=1 + 0.2 * torch.randn(cout, generator=g), beta=0.1 * torch.randn(cout, generator=g),
@@ -793,14 +797,14 @@ def test_conv_resblock_fused_matches_two_launches(case):
     code = _lib.ACT_MISH if act == "mish" else _lib.ACT_LEAKY
     y = torch.full_like(want, float("nan"))
     _lib.launch("ymx_conv_resblock_fused", xin, _lib.ptr(xin), _lib.ptr(w0), _lib.ptr(sc0), _lib.ptr(sh0), _lib.ptr(w1), _lib.ptr(sc1),
-                _lib.ptr(sh1), _lib.ptr(y), B, H, W, code, 0, 0)
+                _lib.ptr(sh1), _lib.ptr(y), B, H, W, C, code, 0, 0)
     assert torch.equal(y, want), float((y.float() - want.float()).abs().max())
     # through the program executor: op 0 marked as read by op 1 alone
     ops = (_lib.ymx_op * 2)()
     y2 = torch.full_like(want, float("nan"))
     mid2 = torch.full_like(mid, float("nan"))
-    for o, (layer, src, dst, k, cin, cout, w, sc, sh) in zip(ops, ((l0, xin, mid2, 1, 64, 32, w0, sc0, sh0),
-                                                                     (l1, mid2, y2, 3, 32, 64, w1, sc1, sh1))):
+    for o, (layer, src, dst, k, cin, cout, w, sc, sh) in zip(ops, ((l0, xin, mid2, 1, C, C // 2, w0, sc0, sh0),
+                                                                     (l1, mid2, y2, 3, C // 2, C, w1, sc1, sh1))):
         o.kind, o.B, o.H, o.W, o.Cin, o.Cout, o.k, o.stride, o.act = 1, B, H, W, cin, cout, k, 1, layer.act_code
         o.dtype = o.out_dtype = o.x_dtype = _lib.BF16
         o.x, o.w, o.y = src.data_ptr(), w.data_ptr(), dst.data_ptr()

@@ -52,7 +52,7 @@ SIGNATURES = {
     "ymx_conv2d_fused_ex": (_i, [_vp] * 6 + [_i] * 14 + [_vp]),
     "ymx_upsample2x_concat": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ymx_conv_stem_fused": (_i, [_vp] * 8 + [_i] * 5 + [_vp]),
-    "ymx_conv_resblock_fused": (_i, [_vp] * 8 + [_i] * 6 + [_vp]),
+    "ymx_conv_resblock_fused": (_i, [_vp] * 8 + [_i] * 7 + [_vp]),
     "ymx_run_program": (_i, [ctypes.POINTER(ymx_op), _i, _vp]),
     "ymx_conv_kernel_label": (ctypes.c_char_p, [ctypes.POINTER(ymx_op)]),
     "ymx_decode_workspace_bytes": (_sz, [_i, _i, ctypes.POINTER(_i)]),

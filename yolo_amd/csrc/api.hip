@@ -370,28 +370,31 @@ int ymx_conv_stem_fused(const void *x, const void *w0, const void *scale0, const
 }
 
 int ymx_conv_resblock_fused(const void *x, const void *w1, const void *scale1, const void *shift1, const void *w2,
-                            const void *scale2, const void *shift2, void *y, int B, int H, int W, int act, int x_ld, int y_ld,
+                            const void *scale2, const void *shift2, void *y, int B, int H, int W, int C, int act, int x_ld, int y_ld,
                             void *stream) {
     if (!x || !w1 || !w2 || !y) return fail(YMX_EARG, "conv_resblock_fused: null pointer");
     if (B <= 0 || H <= 0 || W <= 0) return fail(YMX_EARG, "conv_resblock_fused: B=%d H=%d W=%d", B, H, W);
-    if ((x_ld != 0 && (x_ld < 64 || (x_ld & 7))) || (y_ld != 0 && (y_ld < 64 || (y_ld & 7))))
-        return fail(YMX_EARG, "conv_resblock_fused: x_ld=%d, y_ld=%d (each 0, or a multiple of 8 not below 64)", x_ld, y_ld);
+    if (C != 64 && C != 128) return fail(YMX_EUNSUPPORTED, "conv_resblock_fused: %d channels (64 or 128)", C);
+    if ((x_ld != 0 && (x_ld < C || (x_ld & 7))) || (y_ld != 0 && (y_ld < C || (y_ld & 7))))
+        return fail(YMX_EARG, "conv_resblock_fused: x_ld=%d, y_ld=%d (each 0, or a multiple of 8 not below %d)", x_ld, y_ld, C);
     if (!aligned16(x) || !aligned16(w1) || !aligned16(w2) || !aligned16(y))
         return fail(YMX_EARG, "conv_resblock_fused: x, w1, w2 and y must be 16-byte aligned");
     if (x == y) return fail(YMX_EARG, "conv_resblock_fused: y must not be x (neighbouring tiles read x after this one has written y)");
-    return launch_conv_resblock(x, x_ld, w1, (const float *)scale1, (const float *)shift1, w2, (const float *)scale2,
-                                (const float *)shift2, y, y_ld, B, H, W, act, (hipStream_t)stream);
+    return (C == 64 ? launch_conv_resblock : launch_conv_resblock128)(
+        x, x_ld, w1, (const float *)scale1, (const float *)shift1, w2, (const float *)scale2, (const float *)shift2, y, y_ld, B, H, W, act,
+        (hipStream_t)stream);
 }
 
-// Op i is the 1x1 convolution 64 -> 32 of a ResidialBlock, marked as read by op i + 1 alone, and op
-// i + 1 the 3x3 convolution 32 -> 64 that reads it and adds op i's input: the block the fused kernel takes.
+// Op i is the 1x1 convolution C -> C/2 of a ResidialBlock (C = 64 or 128), marked as read by op i + 1 alone, and
+// op i + 1 the 3x3 convolution C/2 -> C that reads it and adds op i's input: the block the fused kernels take.
 static bool resblock_pair(const ymx_op &o, const ymx_op &n) {
-    return o.kind == 1 && n.kind == 1 && o.C1 != 0 &&
-           o.Cin == 64 && o.Cout == 32 && o.k == 1 && o.stride == 1 && o.dtype == YMX_BF16 && o.x_dtype == YMX_BF16 &&
-           o.out_dtype == YMX_BF16 && !o.residual && (o.y_ld == 0 || o.y_ld == 32) &&
-           n.Cin == 32 && n.Cout == 64 && n.k == 3 && n.stride == 1 && n.dtype == YMX_BF16 && n.x_dtype == YMX_BF16 &&
+    const int C = o.Cin;
+    return o.kind == 1 && n.kind == 1 && o.C1 != 0 && (C == 64 || C == 128) &&
+           o.Cout == C / 2 && o.k == 1 && o.stride == 1 && o.dtype == YMX_BF16 && o.x_dtype == YMX_BF16 &&
+           o.out_dtype == YMX_BF16 && !o.residual && (o.y_ld == 0 || o.y_ld == C / 2) &&
+           n.Cin == C / 2 && n.Cout == C && n.k == 3 && n.stride == 1 && n.dtype == YMX_BF16 && n.x_dtype == YMX_BF16 &&
            n.out_dtype == YMX_BF16 && n.residual == o.x && n.x == o.y && n.y != o.x && n.B == o.B && n.H == o.H && n.W == o.W &&
-           (n.x_ld == 0 || n.x_ld == 32) && (n.res_ld == 0 ? (o.x_ld == 0 || o.x_ld == 64) : n.res_ld == (o.x_ld ? o.x_ld : 64)) &&
+           (n.x_ld == 0 || n.x_ld == C / 2) && (n.res_ld == 0 ? (o.x_ld == 0 || o.x_ld == C) : n.res_ld == (o.x_ld ? o.x_ld : C)) &&
            o.act == n.act && conv_resblock_supported(o.act);
 }
 
@@ -418,7 +421,7 @@ int ymx_run_program(const ymx_op *ops, int n_ops, void *stream) {
         }
         if (rc == YMX_EUNSUPPORTED && i + 1 < n_ops && resblock_pair(o, ops[i + 1])) {
             const ymx_op &n = ops[i + 1];
-            rc = ymx_conv_resblock_fused(o.x, o.w, o.scale, o.shift, n.w, n.scale, n.shift, n.y, o.B, o.H, o.W, o.act, o.x_ld, n.y_ld, stream);
+            rc = ymx_conv_resblock_fused(o.x, o.w, o.scale, o.shift, n.w, n.scale, n.shift, n.y, o.B, o.H, o.W, o.Cin, o.act, o.x_ld, n.y_ld, stream);
             if (rc == YMX_OK) { ++i; continue; }
         }
         if (rc != YMX_EUNSUPPORTED) {

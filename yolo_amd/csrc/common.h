@@ -245,6 +245,8 @@ int launch_conv_stem(const float *x, const float *w0, const float *scale0, const
 bool conv_resblock_supported(int act);
 int launch_conv_resblock(const void *x, int x_ld, const void *w1, const float *scale1, const float *shift1, const void *w2,
                          const float *scale2, const float *shift2, void *y, int y_ld, int B, int H, int W, int act, hipStream_t s);
+int launch_conv_resblock128(const void *x, int x_ld, const void *w1, const float *scale1, const float *shift1, const void *w2,
+                            const float *scale2, const float *shift2, void *y, int y_ld, int B, int H, int W, int act, hipStream_t s);
 int launch_conv_direct(const ConvArgs &a, hipStream_t s);
 int launch_pack_weights(const float *w_hwio, void *w_packed, int k, int Cin, int Cout, int dtype,
                         hipStream_t s, int src_cout = 0);

@@ -41,8 +41,8 @@ class Detector(nn.Module):
         "auto" = time a few cuts once per input shape and keep the fastest, "off" = never,
         or a tuple of sub-batch sizes used for batches of exactly their sum.
         fuse_stem: the backbone's first two layers (backbones.py:11-12) run as one launch that
-        keeps the 32-channel full-resolution map in LDS, and so does its first ResidialBlock
-        (backbones.py:13) with the 32-channel map between its two convolutions (same bits as the
+        keeps the 32-channel full-resolution map in LDS, and so do its first three ResidialBlocks
+        (backbones.py:13-16) with the narrow map between their two convolutions (same bits as the
         separate launches; those maps are then never written, so per-layer hooks on the planned
         path need fuse_stem=False)."""
         super().__init__()
@@ -198,9 +198,10 @@ class Detector(nn.Module):
                     y, _, _ = conv(layer.layer_stack[0], x, h, w)
                     x, h, w = conv(layer.layer_stack[1], y, h, w, residual=x)
                     a, b = ops[first], ops[first + 1]
-                    if self.fuse_stem and (a.Cin, a.Cout, a.k, b.Cout, b.k) == (64, 32, 1, 64, 3) and a.act == b.act:
-                        # ResidialBlock(32, 64): the 32-channel map is read by the 3x3 convolution alone, so
-                        # ymx_run_program may run the block as one launch (ymx_conv_resblock_fused)
+                    if self.fuse_stem and (a.Cin, a.Cout, a.k, b.Cout, b.k) in ((64, 32, 1, 64, 3), (128, 64, 1, 128, 3)) \
+                            and a.act == b.act:
+                        # ResidialBlock(32, 64) / (64, 128): the narrow map is read by the 3x3 convolution alone,
+                        # so ymx_run_program may run the block as one launch (ymx_conv_resblock_fused)
                         a.C1 = 1
                 else:
                     x, h, w = conv(layer, x, h, w, x_code=xc)
