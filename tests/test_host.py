@@ -117,6 +117,48 @@ def test_fused_stem_entry_point_validates_without_gpu():
     assert L.ymx_conv_stem_fused(*args(B=64, H=2048, W=2048)) == -2          # the image batch must stay under 2 GB
 
 
+def test_fused_resblock_entry_point_validates_without_gpu():
+    from yolo_amd import _lib
+    L = _lib.lib()
+    one = ctypes.c_void_p(256)
+    args = lambda **kw: [kw.get("x", one), kw.get("w1", one), None, one, one, None, one, kw.get("y", ctypes.c_void_p(512)),
+                         kw.get("B", 2), kw.get("H", 64), kw.get("W", 64), kw.get("C", 64), kw.get("act", 2),
+                         kw.get("x_ld", 0), kw.get("y_ld", 0), None]
+    assert L.ymx_conv_resblock_fused(*args(x=None)) == -1 and b"null" in L.ymx_last_error()
+    assert L.ymx_conv_resblock_fused(*args(H=0)) == -1
+    assert L.ymx_conv_resblock_fused(*args(C=96)) == -2 and b"channels" in L.ymx_last_error()
+    assert L.ymx_conv_resblock_fused(*args(C=128, x_ld=64)) == -1 and b"x_ld" in L.ymx_last_error()
+    assert L.ymx_conv_resblock_fused(*args(y_ld=68)) == -1
+    assert L.ymx_conv_resblock_fused(*args(w1=ctypes.c_void_p(264))) == -1 and b"aligned" in L.ymx_last_error()
+    assert L.ymx_conv_resblock_fused(*args(y=one)) == -1 and b"must not be x" in L.ymx_last_error()
+    assert L.ymx_conv_resblock_fused(*args(act=0)) == -2 and b"activation" in L.ymx_last_error()
+    assert L.ymx_conv_resblock_fused(*args(B=64, H=2048, W=2048)) == -2          # x must stay under 2 GB
+
+
+def test_wide_tile_plan_labels_are_consistent():
+    """The tile plan of the wide kernels, asked of the library for a sweep of batch sizes: a mixed
+    launch is only chosen for launches of two rounds and more, and forcing a pure form always works."""
+    from yolo_amd import _lib
+    L = _lib.lib()
+    try:
+        for B in range(1, 130, 3):
+            for hw, cin, cout, k in ((52, 512, 1024, 3), (52, 128, 256, 3), (26, 512, 1024, 3), (52, 1024, 512, 1), (13, 512, 1024, 3)):
+                op = _conv_op(B, hw, hw, cin, cout, k, min_tiles=1)
+                tiles = -(-B * hw * hw // 256) * -(-cout // 256)
+                lab = _label(op)
+                assert lab in ("halo", "halo192", "halo_mixed", "dma4", "dma4_192", "dma4_mixed"), (B, hw, lab)
+                if lab.endswith("_mixed"):
+                    assert tiles > 256, (B, hw, cin, cout, tiles)
+                opt = b"halo_pixels" if k == 3 else b"dma4_pixels"
+                for px, want in ((256, ""), (192, "192")):
+                    _lib.check(L.ymx_set_option(opt, px))
+                    assert _label(op) == ("halo" if k == 3 else "dma4") + ("_" if (want and k == 1) else "") + want, (B, hw, px)
+                _lib.check(L.ymx_set_option(opt, 0))
+    finally:
+        _lib.check(L.ymx_set_option(b"halo_pixels", 0))
+        _lib.check(L.ymx_set_option(b"dma4_pixels", 0))
+
+
 def test_module_interface_matches_reference():
     import yolo_amd
     from yolo_amd import layers, backbones, detectors
