@@ -58,9 +58,13 @@ const char *ymx_last_error(void);
  * output channels with at least dma_min_tiles 256-pixel tiles run on the LDS-DMA kernels
  * (2, the default: with the input-resident kernel for 3x3 stride 1 and 32 or 64 input
  * channels; 1: without it) or on the register-staged kernel (0).  "halo_pixels": pixels per
- * tile of the resident-slab 3x3 kernel (0, the default: 192 where that shortens the launch,
- * else 256; 192 or 256 force one; rows longer than 59 pixels always take 192).
- * "dma4_pixels": the same choice for the phase-staggered kernel (0, the default: per layer).
+ * tile of the resident-slab 3x3 kernel (0, the default, chooses per layer among 256, 192 and
+ * both in one launch -- whole rounds of 256-pixel tiles on the chip's CUs, the remaining pixels
+ * as 192-pixel tiles; 192 or 256 force one, 448 the mixed form where the launch has two rounds
+ * or more; rows longer than 59 pixels always take 192).  "dma4_pixels": the same choice for the
+ * phase-staggered kernel.  "tile_mix": 0 restricts the per-layer choice to the two pure forms
+ * (default 1).  "halo_big_rounds": rounds of 256-pixel tiles of a mixed launch (0, the default:
+ * priced per layer).
  * "wgrad_variant": 0 (the default) lets ymx_conv_wgrad choose: the all-taps LDS-DMA kernel for
  * 3x3 stride 1 on rows up to 459 pixels, the all-taps planar-staged kernel for 3x3 stride 2
  * with up to 32 input channels, else the per-tap LDS-DMA kernel, both for x and dz
