@@ -829,3 +829,37 @@ def test_conv_resblock_fused_matches_two_launches(case):
     assert torch.equal(mid2, mid) and torch.equal(y2, l1(mid))
     ref = N.yolo_conv(N.bf16_round(N.yolo_conv(x, params[0], False, act)), params[1], False, act) + x
     assert rel_err(y.float().cpu().numpy(), ref.numpy()) < 2e-2
+
+
+def test_fused_blocks_beside_other_work():
+    """The fused residual-block kernels, repeated while a second stream keeps the GPU busy with other
+    convolutions (workgroups then start at irregular times and share L2 and HBM with foreign
+    traffic): every repetition gives the bits of the first, quiet run."""
+    from yolo_amd import _lib
+    g = torch.Generator().manual_seed(77)
+    side = torch.cuda.Stream()
+    px = torch.randn(24, 26, 26, 256, generator=g).to(DEV).bfloat16()
+    pl = make_conv({"kernel": N.bf16_round(torch.randn(3, 3, 256, 512, generator=g) * 0.02), "bias": torch.zeros(512)},
+                   3, False, "mish", False, torch.bfloat16)
+    for C, S, B in ((64, 208, 16), (128, 104, 32)):
+        x = torch.randn(B, S, S, C, generator=g).to(DEV).bfloat16()
+        p0 = {"kernel": N.bf16_round(torch.randn(1, 1, C, C // 2, generator=g) * (2.0 / C) ** 0.5), "bias": 0.1 * torch.randn(C // 2, generator=g)}
+        p1 = {"kernel": N.bf16_round(torch.randn(3, 3, C // 2, C, generator=g) * (4.0 / (9 * C)) ** 0.5), "bias": 0.1 * torch.randn(C, generator=g)}
+        l0 = make_conv(p0, 1, False, "mish", False, torch.bfloat16)
+        l1 = make_conv(p1, 3, False, "mish", False, torch.bfloat16)
+        want = l1(l0(x), residual=x)
+        w0, sc0, sh0, _ = l0.packed(torch.bfloat16)
+        w1, sc1, sh1, _ = l1.packed(torch.bfloat16)
+        y = torch.empty_like(want)
+        bad = torch.zeros((), device=DEV, dtype=torch.int64)
+        torch.cuda.synchronize()
+        for it in range(40):
+            y.fill_(float("nan"))
+            _lib.launch("ymx_conv_resblock_fused", x, _lib.ptr(x), _lib.ptr(w0), _lib.ptr(sc0), _lib.ptr(sh0), _lib.ptr(w1), _lib.ptr(sc1),
+                        _lib.ptr(sh1), _lib.ptr(y), B, S, S, C, _lib.ACT_MISH, 0, 0)
+            bad += (y.view(torch.int16) != want.view(torch.int16)).sum()
+            with torch.cuda.stream(side):
+                pl(px)
+        side.synchronize()
+        torch.cuda.synchronize()
+        assert int(bad.item()) == 0, (C, int(bad.item()))
