@@ -121,7 +121,9 @@ int ymx_conv2d_fused_ex(const void *x, const void *w, const void *scale, const v
  * centres, edge clamp) fused with the tf.concat that follows it at
  * detectors.py:57-59 and 70-72:  y[..., :C1] = skip,  y[..., C1:] = up2(x).
  * skip [B,2H,2W,C1] (NULL with C1 = 0 for a bare upsample), x [B,H,W,C2],
- * y [B,2H,2W,C1+C2]. */
+ * y [B,2H,2W,C1+C2].  skip = NULL with C1 > 0: the first C1 channels of y are already in
+ * place (the convolution that produces them wrote them there through its y_ld: a concat
+ * without the copy) and only y[..., C1:] is written. */
 int ymx_upsample2x_concat(const void *skip, const void *x, void *y, int B, int H, int W,
                           int C1, int C2, int dtype, void *stream);
 

@@ -349,7 +349,7 @@ int ymx_conv2d_fused_z(const void *x, const void *w, const void *scale, const vo
 
 int ymx_upsample2x_concat(const void *skip, const void *x, void *y, int B, int H, int W, int C1, int C2, int dtype,
                           void *stream) {
-    if (!x || !y || (C1 > 0 && !skip)) return fail(YMX_EARG, "upsample2x_concat: null pointer");
+    if (!x || !y) return fail(YMX_EARG, "upsample2x_concat: null pointer");       // (skip == NULL with C1 > 0: those channels of y are in place)
     if (B <= 0 || H <= 0 || W <= 0 || C1 < 0 || C2 <= 0) return fail(YMX_EARG, "upsample2x_concat: bad size");
     if (dtype != YMX_F32 && dtype != YMX_BF16) return fail(YMX_EARG, "upsample2x_concat: dtype %d", dtype);
     const int kch = dtype == YMX_BF16 ? 8 : 4;

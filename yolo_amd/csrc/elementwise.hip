@@ -15,10 +15,13 @@ upsample2x_concat_kernel(const T *__restrict__ skip, const T *__restrict__ x, T 
     constexpr int KCH = 16 / (int)sizeof(T);
     const int CT = C1 + C2, nch = CT / KCH, nch1 = C1 / KCH;
     const int OH = 2 * H, OW = 2 * W;
-    const size_t total = (size_t)B * OH * OW * nch;
+    // skip == nullptr with C1 > 0: the first C1 channels of y are already in place (their producer wrote
+    // them there); only the resized channels are visited
+    const int first = skip ? 0 : nch1, nloop = nch - first;
+    const size_t total = (size_t)B * OH * OW * nloop;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int ch = (int)(i % nch);
-        const size_t pix = i / nch;
+        const int ch = first + (int)(i % nloop);
+        const size_t pix = i / nloop;
         uint4 out;
         if (ch < nch1) {
             out = *(const uint4 *)(skip + pix * C1 + (size_t)ch * KCH);
@@ -70,7 +73,7 @@ upsample2x_concat_kernel(const T *__restrict__ skip, const T *__restrict__ x, T 
 int launch_upsample2x_concat(const void *skip, const void *x, void *y, int B, int H, int W, int C1,
                              int C2, int dtype, hipStream_t s) {
     const int kch = dtype == YMX_BF16 ? 8 : 4;
-    const size_t total = (size_t)B * 2 * H * 2 * W * ((C1 + C2) / kch);
+    const size_t total = (size_t)B * 2 * H * 2 * W * (((skip ? C1 : 0) + C2) / kch);
     const size_t blocks = (total + 255) / 256;
     const int grid = (int)(blocks < 16384 ? blocks : 16384);
     if (dtype == YMX_BF16)

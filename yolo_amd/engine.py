@@ -148,7 +148,11 @@ class Detector(nn.Module):
             keep.append(t)
             return t
 
-        def conv(layer, x, h, w, residual=None, x_code=code, out_dtype=cdt, head=None):
+        def ld(t):
+            """Pixel stride (elements) of a tensor that is a channel slice of a wider buffer; 0 = dense."""
+            return 0 if t is None or t.stride(2) == t.shape[3] else t.stride(2)
+
+        def conv(layer, x, h, w, residual=None, x_code=code, out_dtype=cdt, head=None, out=None):
             oh, ow = layer.output_hw(h, w)
             cout = layer.filters
             if head is not None and cout % 8:
@@ -159,7 +163,11 @@ class Detector(nn.Module):
                 # vector store path; the caller sees the first `filters` channels as a view.
                 cout = (cout + 7) // 8 * 8
             sites.append((len(ops), layer, cout - layer.filters))
-            if head is None:
+            if out is not None:
+                y = out                 # a channel slice of a concat buffer: the concat costs no copy
+                if tuple(y.shape) != (n, oh, ow, cout) or y.dtype != out_dtype:
+                    raise RuntimeError("Detector: concat slice %s does not match the layer's output" % (tuple(y.shape),))
+            elif head is None:
                 y = buf(oh, ow, cout, out_dtype)
             else:
                 # the three output maps are whole-batch buffers owned by the plan
@@ -171,7 +179,7 @@ class Detector(nn.Module):
             o.B, o.H, o.W, o.Cin, o.Cout = n, h, w, layer.in_channels, cout
             o.k, o.stride, o.act = layer.kernel_size, 2 if layer.downsample else 1, layer.act_code
             o.dtype, o.x_dtype, o.out_dtype = code, x_code, _lib.dtype_code(out_dtype)
-            o.x_ld = o.res_ld = o.y_ld = 0
+            o.x_ld, o.res_ld, o.y_ld = ld(x), ld(residual), ld(y)
             o.min_tiles = min_tiles
             o.x = None if x is None else x.data_ptr()
             o.residual = None if residual is None else residual.data_ptr()
@@ -181,22 +189,26 @@ class Detector(nn.Module):
             ops.append(o)
             return y, oh, ow
 
-        def upcat(skip, x, h, w, c1, c2):
-            y = buf(2 * h, 2 * w, c1 + c2)
+        def upcat(cat, x, h, w, c1, c2):
+            """cat [n, 2h, 2w, c1 + c2] already holds the skip tensor in its first c1 channels (its producer
+            wrote it there); the resized x goes into the rest."""
             o = _lib.ymx_op()
             o.kind = 2
             o.B, o.H, o.W, o.C1, o.C2, o.dtype = n, h, w, c1, c2, code
-            o.residual, o.x, o.y = skip.data_ptr(), x.data_ptr(), y.data_ptr()
+            o.residual, o.x, o.y = None, x.data_ptr(), cat.data_ptr()
             ops.append(o)
-            return y
+            return cat
 
-        def run_stack(stack, x, h, w, first_x_code=code):
+        def run_stack(stack, x, h, w, first_x_code=code, out_last=None):
+            """out_last: where the stack's last convolution writes (a channel slice of a concat buffer)."""
             xc = first_x_code
-            for layer in stack:
+            stack = list(stack)
+            for li, layer in enumerate(stack):
+                out = out_last if li == len(stack) - 1 else None
                 if isinstance(layer, ResidialBlock):
                     first = len(ops)
                     y, _, _ = conv(layer.layer_stack[0], x, h, w)
-                    x, h, w = conv(layer.layer_stack[1], y, h, w, residual=x)
+                    x, h, w = conv(layer.layer_stack[1], y, h, w, residual=x, out=out)
                     a, b = ops[first], ops[first + 1]
                     if self.fuse_stem and (a.Cin, a.Cout, a.k, b.Cout, b.k) in ((64, 32, 1, 64, 3), (128, 64, 1, 128, 3)) \
                             and a.act == b.act:
@@ -204,23 +216,34 @@ class Detector(nn.Module):
                         # so ymx_run_program may run the block as one launch (ymx_conv_resblock_fused)
                         a.C1 = 1
                 else:
-                    x, h, w = conv(layer, x, h, w, x_code=xc)
+                    x, h, w = conv(layer, x, h, w, x_code=xc, out=out)
                 xc = code
             return x, h, w
 
         bb, hd = self.backbone, self.head
         # op 0 reads the caller's image tensor; its pointer is patched on every call
-        s1, h1, w1 = run_stack(bb.layer_stack_1, None, S, S, first_x_code=_lib.dtype_code(x_dtype))
-        s2, h2, w2 = run_stack(bb.layer_stack_2, s1, h1, w1)
+        # The two concats of the head (detectors.py:59, 72) cost no copy: the backbone's last block of a
+        # scale writes its output straight into the first channels of the concat buffer (pixel stride =
+        # the buffer's), the next backbone stage reads it from there, and the upsample kernel fills the rest.
+        def last_filters(stack):
+            last = list(stack)[-1]
+            return (last.layer_stack[1] if isinstance(last, ResidialBlock) else last).filters
+        c_s1, c_s2 = last_filters(bb.layer_stack_1), last_filters(bb.layer_stack_2)
+        c_u2, c_u1 = last_filters(hd.layer_stack_1), last_filters(hd.layer_stack_2)
+        cat1 = torch.empty((n, S // 8, S // 8, c_s1 + c_u1), device=device, dtype=cdt)
+        cat2 = torch.empty((n, S // 16, S // 16, c_s2 + c_u2), device=device, dtype=cdt)
+        s1, h1, w1 = run_stack(bb.layer_stack_1, None, S, S, first_x_code=_lib.dtype_code(x_dtype), out_last=cat1[..., :c_s1])
+        s2, h2, w2 = run_stack(bb.layer_stack_2, s1, h1, w1, out_last=cat2[..., :c_s2])
         s3, h3, w3 = run_stack(bb.layer_stack_3, s2, h2, w2)
         x, _, _ = run_stack(hd.layer_stack_1, s3, h3, w3)
         l, _, _ = conv(hd.lbbox_layer_stack[0], x, h3, w3)
         l, _, _ = conv(hd.lbbox_layer_stack[1], l, h3, w3, out_dtype=hd.out_dtype, head=2)
-        x = upcat(s2, x, h3, w3, s2.shape[-1], x.shape[-1])
+        x = upcat(cat2, x, h3, w3, c_s2, x.shape[-1])
         x, _, _ = run_stack(hd.layer_stack_2, x, h2, w2)
         m, _, _ = conv(hd.mbbox_layer_stack[0], x, h2, w2)
         m, _, _ = conv(hd.mbbox_layer_stack[1], m, h2, w2, out_dtype=hd.out_dtype, head=1)
-        s = upcat(s1, x, h2, w2, s1.shape[-1], x.shape[-1])
+        s = upcat(cat1, x, h2, w2, c_s1, x.shape[-1])
+        keep.extend([cat1, cat2])       # (after the per-layer buffers, whose order tools rely on)
         s, _, _ = run_stack(list(hd.sbbox_layer_stack)[:-1], s, h1, w1)
         s, _, _ = conv(hd.sbbox_layer_stack[-1], s, h1, w1, out_dtype=hd.out_dtype, head=0)
 
