@@ -264,51 +264,59 @@ def test_conv_dma_kernel_forced(case):
         _lib.check(L.ymx_set_option(b"dma4_pixels", 0))
 
 
-MIXED_SHAPES = [   # B, H, W, Cin, Cout, activation, shortcut: launches of two to four rounds of 256-pixel tiles
-    (64, 52, 52, 128, 256, "mish", True),        # 676 tiles: 512 of 256 pixels + 219 of 192
-    (61, 26, 26, 128, 1000, "leaky", False),     # partial last pixel tile of the 192-pixel part, partial channel tile
-    (33, 40, 40, 64, 512, "mish", True),         # 207 pixel tiles x 2: one whole round of 256-pixel tiles, ragged rest
+MIXED_SHAPES = [   # B, H, W, Cin, Cout, activation, shortcut, k, stride: launches of two to four rounds of 256-pixel tiles
+    (64, 52, 52, 128, 256, "mish", True, 3, 1),        # 676 tiles: 512 of 256 pixels + 219 of 192
+    (61, 26, 26, 128, 1000, "leaky", False, 3, 1),     # partial last pixel tile of the 192-pixel part, partial channel tile
+    (33, 40, 40, 64, 512, "mish", True, 3, 1),         # 207 pixel tiles x 2: one whole round of 256-pixel tiles, ragged rest
+    (64, 52, 52, 256, 512, "mish", True, 1, 1),        # the phase-staggered kernel: 1x1, 1 352 tiles
+    (37, 52, 52, 192, 264, "leaky", False, 1, 1),      # ragged pixels and channels, K = 192
+    (64, 104, 104, 64, 256, "mish", False, 3, 2),      # stride 2, 676 tiles
 ]
 
 
 @pytest.mark.parametrize("case", range(len(MIXED_SHAPES)))
 def test_conv_halo_mixed_tiles(case):
-    """The resident-slab kernel with both tile forms in one launch (whole rounds of 256-pixel tiles,
-    the remaining pixels as 192-pixel tiles): the same bits as either pure form, bf16 and fp32
-    outputs, and the layer's own choice among the three is one of them."""
+    """The wide kernels (resident-slab 3x3; phase-staggered 1x1 and stride 2) with both tile forms in
+    one launch (whole rounds of 256-pixel tiles, the remaining pixels as 192-pixel tiles): the same
+    bits as either pure form, bf16 and fp32 outputs, and the layer's own choice among the three is
+    one of them."""
     from yolo_amd import _lib
-    B, H, W, cin, cout, act, use_res = MIXED_SHAPES[case]
+    B, H, W, cin, cout, act, use_res, k, stride = MIXED_SHAPES[case]
     g = torch.Generator().manual_seed(700 + case)
     xin = torch.randn(B, H, W, cin, generator=g).to(DEV).bfloat16()
-    p = {"kernel": N.bf16_round(torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5),
+    p = {"kernel": N.bf16_round(torch.randn(k, k, cin, cout, generator=g) * (2.0 / (k * k * cin)) ** 0.5),
          "bias": 0.1 * torch.randn(cout, generator=g)}
-    rin = torch.randn(B, H, W, cout, generator=g).to(DEV).bfloat16() if use_res else None
-    layer = make_conv(p, 3, False, act, False, torch.bfloat16)
+    oh, ow = (H, W) if stride == 1 else ((H + 1 - k) // 2 + 1, (W + 1 - k) // 2 + 1)
+    rin = torch.randn(B, oh, ow, cout, generator=g).to(DEV).bfloat16() if use_res else None
+    layer = make_conv(p, k, stride == 2, act, False, torch.bfloat16)
+    halo = k == 3 and stride == 1
+    opt = b"halo_pixels" if halo else b"dma4_pixels"
+    names = {256: "halo", 192: "halo192", 448: "halo_mixed"} if halo else {256: "dma4", 192: "dma4_192", 448: "dma4_mixed"}
     L = _lib.lib()
     op = _lib.ymx_op()
-    op.kind, op.B, op.H, op.W, op.Cin, op.Cout, op.k, op.stride = 1, B, H, W, cin, cout, 3, 1
+    op.kind, op.B, op.H, op.W, op.Cin, op.Cout, op.k, op.stride = 1, B, H, W, cin, cout, k, stride
     op.dtype = op.x_dtype = op.out_dtype = _lib.BF16
     op.x = op.w = op.y = 256
     import ctypes
     try:
         outs = {}
         for pixels in (256, 192, 448):
-            _lib.check(L.ymx_set_option(b"halo_pixels", pixels))
-            assert L.ymx_conv_kernel_label(ctypes.byref(op)).decode() == {256: "halo", 192: "halo192", 448: "halo_mixed"}[pixels]
+            _lib.check(L.ymx_set_option(opt, pixels))
+            assert L.ymx_conv_kernel_label(ctypes.byref(op)).decode() == names[pixels]
             outs[pixels] = (layer(xin, residual=rin).clone(), layer(xin, residual=rin, out_dtype=torch.float32).clone())
         for pixels in (192, 448):
             assert torch.equal(outs[pixels][0], outs[256][0]), pixels
             assert torch.equal(outs[pixels][1], outs[256][1]), pixels
-        _lib.check(L.ymx_set_option(b"halo_pixels", 0))
+        _lib.check(L.ymx_set_option(opt, 0))
         assert torch.equal(layer(xin, residual=rin), outs[256][0])
         # against the oracle on a slice of the batch (first and last image)
         for b in (0, B - 1):
-            want = N.yolo_conv(xin[b:b + 1].float().cpu(), p, False, act)
+            want = N.yolo_conv(xin[b:b + 1].float().cpu(), p, stride == 2, act)
             if use_res:
                 want = want + rin[b:b + 1].float().cpu()
             assert rel_err(outs[448][1][b:b + 1].cpu().numpy(), want.numpy()) < 1e-3
     finally:
-        _lib.check(L.ymx_set_option(b"halo_pixels", 0))
+        _lib.check(L.ymx_set_option(opt, 0))
 
 
 STEM_CASES = [   # B, H, W, activation, batch norm
