@@ -7,10 +7,14 @@
 // the wider 3x3 convolution forces: its weights are 144 KB, too many for LDS beside the tile, so
 // they live in REGISTERS, split by output channel:
 //
-//   phase A   the 180 pixels of the 64-channel tile, 16 at a time per wave: a lane loads 4 x 16
-//             bytes of its pixel's 128 input channels straight into MFMA B operands, the 1x1 weights
-//             come from LDS (16 KB); K = 128 as four MFMAs per 16-channel group, in the K order of the
-//             packed weights; affine + activation on pairs, one rounding, 16 bytes per lane into LDS
+//   input     the tile's 180 input pixels x 128 channels (45 KB) come into LDS by LDS-DMA, 4 pixels per
+//             instruction, issued a whole tile ahead: no register holds them, and both the 1x1
+//             convolution and the shortcut read them there (x is read from memory exactly once; a first
+//             version that loaded them per lane spent a fifth of its time issuing those loads)
+//   phase A   the 180 pixels of the 64-channel tile, 16 at a time per wave: MFMA B operands from the
+//             input tile, the 1x1 weights from LDS (16 KB); K = 128 as four MFMAs per 16-channel group,
+//             in the K order of the packed weights; affine + activation on pairs, one rounding, 16
+//             bytes per lane into LDS
 //   phase B   wave w owns output channels 16w .. 16w+15 for ALL 128 pixels of the tile: its 18 weight
 //             fragments (9 taps x 2 halves of the 64 input channels) stay in 72 registers for the
 //             workgroup's life; it walks the 10 tile rows, and every pixel fragment it reads (row m,
@@ -18,13 +22,12 @@
 //             tap of: 60 LDS reads for 144 MFMAs.  Per accumulator the K terms arrive tap by tap,
 //             the two channel halves inside a tap -- the order of the packed weights, so the same bits
 //             as conv_igemm_slab2.hip
-//   epilogue  affine, activation, shortcut (8-byte loads issued before phase B) added in fp32, one
+//   epilogue  affine, activation, shortcut (read from the input tile before it is overwritten) added in fp32, one
 //             rounding, in the accumulator layout; the bf16 results of all eight waves meet in a
 //             32 KB LDS image of the output tile and leave as 16-byte stores, 256 contiguous bytes
 //             per pixel
 //
-// 212 registers, one workgroup (8 waves) per CU, persistent; a wave fetches the operands of its
-// blocks of the next tile before phase B of the current one.
+// 218 registers, 116 KB of LDS, one workgroup (8 waves) per CU, persistent.
 #include "conv_epilogue.h"
 
 namespace ymx {
@@ -39,7 +42,9 @@ constexpr int RC_MIDB = RC_MR * RC_ROWB;                  // 23 040
 constexpr int RC_W1B = 64 * 256;                          // 1x1 weights: 64 output channels x 128 bf16
 constexpr int RC_STAGEB = RC_TH * RC_TW * 256;            // output tile: 128 pixels x 128 bf16
 constexpr int RC_AFFB = 2 * 64 * 4;                       // scale and shift of the 1x1 convolution
-constexpr int RC_LDS = RC_MIDB + RC_W1B + RC_STAGEB + RC_AFFB;
+constexpr int RC_NPX = RC_MR * RC_MC;                     // 180 pixels of the tile with its halo
+constexpr int RC_XB = RC_NPX * 256;                       // their 128 input channels: 45 KB, 45 LDS-DMA instructions of 4 pixels
+constexpr int RC_LDS = RC_XB + RC_MIDB + RC_W1B + RC_STAGEB + RC_AFFB;
 
 struct ResBlock128Args {
     const bf16_t *x;                // [B,H,W,128] bf16, pixel stride x_ld
@@ -61,15 +66,17 @@ template <int ACT>
 __global__ void __launch_bounds__(512, 2)
 conv_resblock128_kernel(const ResBlock128Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *const mid = smem;                                   // pixel (row, col) at row * RC_ROWB + col * 128, 16-byte slot s at (s ^ (col & 7)) * 16
-    char *const w1s = smem + RC_MIDB;                         // output channel n at n * 256, 16-byte slot s (8 input channels) at (s ^ (n & 15)) * 16
-    char *const stage = smem + RC_MIDB + RC_W1B;              // output pixel p = 16 row + col at p * 256, slot s at (s ^ (p & 15)) * 16
-    float *const aff1 = (float *)(smem + RC_MIDB + RC_W1B + RC_STAGEB);
+    char *const xs = smem;                                    // input pixel q = 18 row + col of the tile at q * 256, 16-byte slot s holds channels 8 (s ^ (q & 15)) .. + 7
+    char *const mid = smem + RC_XB;                           // pixel (row, col) at row * RC_ROWB + col * 128, 16-byte slot s at (s ^ (col & 7)) * 16
+    char *const w1s = mid + RC_MIDB;                          // output channel n at n * 256, 16-byte slot s (8 input channels) at (s ^ (n & 15)) * 16
+    char *const stage = w1s + RC_W1B;                         // output pixel p = 16 row + col at p * 256, slot s at (s ^ (p & 15)) * 16
+    float *const aff1 = (float *)(stage + RC_STAGEB);
+    const unsigned xs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int g = lane >> 4, li = lane & 15;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const i32x4_t xrsrc = make_rsrc(a.x, a.x_bytes);
     constexpr unsigned OOB = 0x80000000u;
 
     // ---- 1x1 weights and its affine parameters into LDS ----
@@ -128,28 +135,48 @@ conv_resblock128_kernel(const ResBlock128Args a) {
     };
     const unsigned xpix = (unsigned)a.x_ld * 2u;             // bytes per pixel of x
 
-    // operand gather of one block: lane (pixel li, K group g) loads channels 32 kk + 8g .. + 7 for kk = 0 .. 3
-    auto issue = [&](const Tile &tl, int blk, uint4 (&p)[4]) {
-        if (!tl.live || blk >= RC_NBLK) return;
-        int mr, mc;
-        bool valid;
-        block_px(blk, mr, mc, valid);
-        if (tl.border) {
-            const int iy = tl.r0 - 1 + mr, ix = tl.c0 - 1 + mc;
-            valid = valid && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        }
-        const unsigned off = valid ? (unsigned)(tl.base + mr * a.W + mc) * xpix + (unsigned)(g * 16) : OOB;
+    // The tile's input pixels come in by LDS-DMA, 4 pixels (1 KB) per instruction and 45 instructions per tile:
+    // instruction i = wave + 8 j, lane l fetches pixel q = 4 i + (l >> 4), channels 8 c .. 8 c + 7 with
+    // c = (l & 15) ^ (q & 15) (the swizzle on the source side), and the hardware puts lane l's 16 bytes at 1024 i + 16 l.
+    // No register holds them, so a whole tile is in flight while the previous one is being computed; pixels
+    // outside the image are out-of-range offsets, for which zeros arrive.
+    int dq_row[6], dq_col[6];
+    unsigned dq_off[6];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            p[kk] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, valid ? off + (unsigned)(kk * 64) : OOB, 0, 0));
+    for (int j = 0; j < 6; ++j) {
+        const int q = 4 * (wave + 8 * j) + (lane >> 4);
+        dq_row[j] = q / RC_MC;
+        dq_col[j] = q - dq_row[j] * RC_MC;
+        dq_off[j] = (unsigned)(dq_row[j] * a.W + dq_col[j]) * xpix + (unsigned)((((lane & 15) ^ (q & 15))) << 4);
+    }
+    auto issue = [&](const Tile &tl) {
+        if (!tl.live) return;
+        const unsigned base = (unsigned)tl.base * xpix;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int i = wave + 8 * j;
+            if (i * 4 >= RC_NPX) continue;
+            unsigned off = base + dq_off[j];
+            if (tl.border) {
+                const int iy = tl.r0 - 1 + dq_row[j], ix = tl.c0 - 1 + dq_col[j];
+                if (!((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)) off = OOB;
+            }
+            lds_dma16(xrsrc, xs_lds + (unsigned)(i * 1024), off);
+        }
     };
     // Row li of MFMA (group q, half tt) is output channel 32 q + 8 (li >> 2) + 4 tt + (li & 3), so that a lane's
     // accumulators of a group (rows 4g .. 4g+3 of both halves) are the 8 consecutive channels 32 q + 8g .. + 7.
     const int w1row = 8 * (li >> 2) + (li & 3);               // + 32 q + 4 tt
-    auto compute = [&](const Tile &tl, int blk, const uint4 (&p)[4]) {
+    auto compute = [&](const Tile &tl, int blk) {
         int mr, mc;
         bool valid;
         block_px(blk, mr, mc, valid);
+        uint4 p[4];
+        {
+            const int q = valid ? mr * RC_MC + mc : 0;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) p[kk] = *(const uint4 *)(xs + q * 256 + (((kk * 4 + g) ^ (q & 15)) << 4));
+        }
         bool inside = true;
         if (tl.border) {
             const int iy = tl.r0 - 1 + mr, ix = tl.c0 - 1 + mc;
@@ -190,30 +217,37 @@ conv_resblock128_kernel(const ResBlock128Args a) {
     const int st_wslot = ((2 * wave + (g >> 1)) ^ li) << 4;
 
     const int nb = (RC_NBLK - wave + 7) / 8;                   // blocks of this wave per tile: wave, wave + 8
-    uint4 pa[4], pb[4];
+    // the shortcut of this lane's output pixels (row, column li): tile pixel (row + 1, li + 1), channels 16 wave + 4g .. + 3
+    int sc_off[RC_TH];
+#pragma unroll
+    for (int row = 0; row < RC_TH; ++row) {
+        const int q = (row + 1) * RC_MC + li + 1;
+        sc_off[row] = q * 256 + (((2 * wave + (g >> 1)) ^ (q & 15)) << 4) + (g & 1) * 8;
+    }
     Tile cur = tile_of(blockIdx.x);
-    issue(cur, wave, pa);
-    if (nb > 1) issue(cur, wave + 8, pb);
-    __syncthreads();                                           // the 1x1 weights are in LDS
+    issue(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                           // the 1x1 weights and the first tile's pixels are in LDS
 
+    YMX_REGION_DECL;
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         // ---- phase A ----
-        compute(cur, wave, pa);
-        if (nb > 1) compute(cur, wave + 8, pb);
+        YMX_REGION_BEGIN(1);
+        compute(cur, wave);
+        if (nb > 1) compute(cur, wave + 8);
+        YMX_REGION_END(1);
+        YMX_REGION_BEGIN(2);
         const Tile nxt = tile_of(tile + gridDim.x);
-        issue(nxt, wave, pa);                                  // land during phase B and the epilogue
-        if (nb > 1) issue(nxt, wave + 8, pb);
-        // the shortcut: output pixels (row, column li) of all eight rows, channels 16 wave + 4g .. + 3
         rc_u32x2_t res[RC_TH];
-        const int oc = cur.c0 + li;
 #pragma unroll
-        for (int row = 0; row < RC_TH; ++row) {
-            const int orow = cur.r0 + row;
-            const bool in = orow < a.H && oc < a.W;
-            const unsigned off = in ? (unsigned)((cur.b * a.H + orow) * a.W + oc) * xpix + (unsigned)((16 * wave + 4 * g) * 2) : OOB;
-            res[row] = __builtin_bit_cast(rc_u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0));
-        }
-        __syncthreads();                                       // the tile is complete (and every wave has read the last output image)
+        for (int row = 0; row < RC_TH; ++row) res[row] = *(const rc_u32x2_t *)(xs + sc_off[row]);
+        YMX_REGION_END(2);
+        YMX_REGION_BEGIN(3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                       // the tile is complete, every wave is done with the input pixels
+        issue(nxt);                                            // the next tile's pixels: they land during phase B and the epilogue
+        YMX_REGION_END(3);
+        YMX_REGION_BEGIN(4);
 
         // ---- phase B: tile rows m = 0 .. 9, each fragment used by the output rows m - r it is tap row r of ----
         f32x4_t acc[RC_TH];
@@ -234,6 +268,8 @@ conv_resblock128_kernel(const ResBlock128Args a) {
                     }
                 }
 
+        YMX_REGION_END(4);
+        YMX_REGION_BEGIN(5);
         // ---- epilogue ----
 #pragma unroll
         for (int row = 0; row < RC_TH; ++row) {
@@ -245,7 +281,12 @@ conv_resblock128_kernel(const ResBlock128Args a) {
             o1 = epi_add2(o1, f32x2_t{__uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u)});
             *(rc_u32x2_t *)(stage + row * 4096 + st_w + st_wslot) = rc_u32x2_t{epi_pack2(o0), epi_pack2(o1)};
         }
-        __syncthreads();                                       // the output image is complete; every wave is done with the tile
+        YMX_REGION_END(5);
+        YMX_REGION_BEGIN(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's part of the next tile's pixels has landed
+        __syncthreads();                                       // the output image and the next input tile are complete
+        YMX_REGION_END(6);
+        YMX_REGION_BEGIN(7);
         {
             const int orow = cur.r0 + wave;
             if (orow < a.H) {
@@ -258,8 +299,10 @@ conv_resblock128_kernel(const ResBlock128Args a) {
                 }
             }
         }
+        YMX_REGION_END(7);
         cur = nxt;
     }
+    YMX_REGION_STORE(wave, lane);
 }
 
 int launch_conv_resblock128(const void *x, int x_ld, const void *w1, const float *scale1, const float *shift1, const void *w2,
@@ -294,3 +337,7 @@ int launch_conv_resblock128(const void *x, int x_ld, const void *w1, const float
 }
 
 }  // namespace ymx
+
+#ifdef YMX_REGION_RB128
+YMX_REGION_EXPORT
+#endif
